@@ -1,0 +1,100 @@
+"""numpy restatement of the device RNG streams -- TEST INFRASTRUCTURE ONLY.
+
+The reference has no device RNG (it uses numpy's global MT19937,
+manytor.py:216,231); the build adds a counter-based Philox-4x32-10 generator
+for benchmark mode so that results do not depend on how envs are sharded over
+GPUs.  This file restates (a) Philox-4x32-10 as published by Salmon et al.,
+"Parallel random numbers: as easy as 1, 2, 3" (SC'11), pinned by the Random123
+known-answer vectors in tests/test_oracle_golden.py, and (b) the two stream
+definitions of manytor_amd/csrc/philox.h, so the HIP kernels can be checked
+bit-for-bit.
+
+Stream definitions (key = (seed_lo, seed_hi)):
+  counter = (env_lo, (env_hi & 0x00FFFFFF) | tag << 24, major, minor)
+  actions : tag 1, major = step index, minor = block (joints 4*block..4*block+3)
+            angle_j = float(mulhi32(u_j, 360)) - 180      -> integer degrees in [-180, 180)
+  targets : tag 2, major = episode index, minor = draw index (0,1,2,...)
+            u01(w) = (w >> 8) * 2^-24
+            x = 2R*u01(w0) - R ; y = 2R*u01(w1) - R ; z = R*u01(w2)   (fp32, one rounding per op)
+            accept iff (x*x + y*y) + z*z <= R*R                     (fp32, one rounding per op)
+            (z is drawn from [0,R) directly: conditioning the reference's
+             uniform(-R,R) on z >= 0, manytor.py:232, gives the same law.)
+"""
+from __future__ import annotations
+
+import numpy as np
+
+M0 = np.uint64(0xD2511F53)
+M1 = np.uint64(0xCD9E8D57)
+W0 = 0x9E3779B9
+W1 = 0xBB67AE85
+MASK = np.uint64(0xFFFFFFFF)
+
+TAG_ACTION = 1
+TAG_TARGET = 2
+
+
+def philox4x32_10(c0, c1, c2, c3, k0, k1):
+    """Vectorised Philox-4x32-10.  All args broadcastable uint32 arrays.
+    Returns 4 uint32 arrays."""
+    c0, c1, c2, c3 = (np.asarray(v, dtype=np.uint64) & MASK for v in np.broadcast_arrays(c0, c1, c2, c3))
+    k0 = int(k0) & 0xFFFFFFFF
+    k1 = int(k1) & 0xFFFFFFFF
+    for _ in range(10):
+        p0 = M0 * c0
+        p1 = M1 * c2
+        hi0, lo0 = p0 >> np.uint64(32), p0 & MASK
+        hi1, lo1 = p1 >> np.uint64(32), p1 & MASK
+        c0, c1, c2, c3 = hi1 ^ c1 ^ np.uint64(k0), lo1, hi0 ^ c3 ^ np.uint64(k1), lo0
+        k0 = (k0 + W0) & 0xFFFFFFFF
+        k1 = (k1 + W1) & 0xFFFFFFFF
+    return tuple(v.astype(np.uint32) for v in (c0, c1, c2, c3))
+
+
+def _ctr(env_ids, tag):
+    env_ids = np.asarray(env_ids, dtype=np.uint64)
+    lo = env_ids & MASK
+    hi = ((env_ids >> np.uint64(32)) & np.uint64(0x00FFFFFF)) | np.uint64(tag << 24)
+    return lo, hi
+
+
+def sample_actions(seed, env_ids, step_idx, dof):
+    """(N, dof) float32 integer-valued degrees in [-180, 180)."""
+    lo, hi = _ctr(env_ids, TAG_ACTION)
+    out = np.empty((lo.shape[0], dof), dtype=np.float32)
+    for blk in range((dof + 3) // 4):
+        w = philox4x32_10(lo, hi, np.uint64(step_idx & 0xFFFFFFFF), np.uint64(blk), seed & 0xFFFFFFFF, seed >> 32)
+        for j in range(4):
+            col = 4 * blk + j
+            if col < dof:
+                v = (w[j].astype(np.uint64) * np.uint64(360)) >> np.uint64(32)
+                out[:, col] = v.astype(np.float32) - np.float32(180.0)
+    return out
+
+
+def sample_targets(seed, env_ids, episode_idx, obj_number, radius):
+    """(N, K, 3) float32 targets by per-env rejection sampling."""
+    lo, hi = _ctr(env_ids, TAG_TARGET)
+    n = lo.shape[0]
+    r = np.float32(radius)
+    r2 = np.float32(2.0) * r
+    rr = r * r
+    out = np.zeros((n, obj_number, 3), dtype=np.float32)
+    cnt = np.zeros(n, dtype=np.int64)
+    draw = 0
+    scale = np.float32(2.0 ** -24)
+    while (cnt < obj_number).any():
+        w = philox4x32_10(lo, hi, np.uint64(episode_idx & 0xFFFFFFFF), np.uint64(draw), seed & 0xFFFFFFFF, seed >> 32)
+        u = [(w[j] >> np.uint32(8)).astype(np.float32) * scale for j in range(3)]
+        x = r2 * u[0] - r
+        y = r2 * u[1] - r
+        z = r * u[2]
+        n2 = (x * x + y * y) + z * z
+        ok = (n2 <= rr) & (cnt < obj_number)
+        idx = np.nonzero(ok)[0]
+        out[idx, cnt[idx], 0] = x[idx]
+        out[idx, cnt[idx], 1] = y[idx]
+        out[idx, cnt[idx], 2] = z[idx]
+        cnt[idx] += 1
+        draw += 1
+    return out
