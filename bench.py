@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: env-steps/sec of the batched manipulator step on MI355X.
+
+    python bench.py                                   # 1 GPU, 1 048 576 arms, 4-DoF, K=7
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one Environment.step() (manytor.py:255-260: 25 interpolated sub-steps of DH forward
+kinematics, ground flag, observation, pickup, reward, return) for EVERY env of the batch, with the
+random action drawn in the same launch (manytor.py:215-217).  Inputs are synthetic and already
+resident in HBM when the timed region starts.  Every `episode_len` steps the returns are gathered
+over the ranks (RCCL all-gather, the only collective) and all envs are reset (test_multi.py:32-34).
+
+Prints ONE JSON line on rank 0 (contract: see the task brief / DESIGN.md section "Measurement").
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+METRIC = "env-steps/sec (whole node), 1M parallel 4-DoF arms, random actions"
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+
+
+def algorithmic_bytes_per_env_step(dof, k):
+    """reads action 4D + goals 4D + points 12K + alive 4 + return 4; writes goals 4D +
+    obs 12K + reward 4 + done 1 + alive 4 + return 4 + end effector 12."""
+    return 12 * dof + 24 * k + 33
+
+
+def cpu_baseline(dof_table, k, budget_s=12.0, n=65536):
+    """The numpy port of the step path (oracle/, parity-checked against the reference's fixtures), timed on
+    this box's host cores on a bounded sample of the same workload.  Baseline, not the target."""
+    from oracle import manytor_oracle as mo
+    from oracle import philox_ref as px
+    table = np.asarray(dof_table)
+    ids = np.arange(n, dtype=np.uint64)
+    ora = mo.BatchOracle(n, k, table=table)
+    ora.reset(px.sample_targets(0x5EED, ids, 0, k, 51.3).astype(np.float64))
+    acts = [px.sample_actions(0x5EED, ids, t, table.shape[0]).astype(np.float64) for t in range(64)]
+    ora.step(acts[0])                                   # warm-up
+    t0 = time.perf_counter()
+    steps = 0
+    while steps < 2 or (time.perf_counter() - t0 < budget_s and steps < 63):
+        ora.step(acts[1 + steps])
+        steps += 1
+    dt = time.perf_counter() - t0
+    return {
+        "value": n * steps / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
+        "sample": f"{n} envs x {steps} steps, vectorised numpy fp64 (oracle/manytor_oracle.py BatchOracle), "
+                  f"{dt:.1f} s on 1 of {os.cpu_count()} host cores",
+    }
+
+
+def load_traffic(workload_key):
+    """HBM bytes per step launch from the committed PMC run (profiles/), or None."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get(workload_key, {}).get("hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--envs-per-gpu", type=int, default=1048576)
+    ap.add_argument("--dof", type=int, default=4, choices=(4, 7))
+    ap.add_argument("--targets", type=int, default=7)
+    ap.add_argument("--episode-len", type=int, default=50)       # test_multi.py:8
+    ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x5EED)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--hw-trig", action="store_true")
+    ap.add_argument("--dh-in-lds", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import manytor_amd as m
+    from manytor_amd import distributed as D
+
+    rank, local_rank, world = D.env_from_torchrun()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available() or m.device_count() < 1:
+        raise SystemExit("bench.py needs a GPU: the step path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    D.init_process_group("nccl" if world > 1 else None)
+
+    n_local = args.envs_per_gpu
+    n_total = n_local * world                                   # weak scaling: per-GPU work fixed
+    base = rank * n_local
+    table = m.REF_DH_TABLE if args.dof == 4 else m.DH7_TABLE
+    radius = 51.3 if args.dof == 4 else 92.6
+    eng = m.StepEngine(n_local, args.targets, dh_table=table, radius=radius, device=local_rank, env_id_base=base,
+                       hw_trig=args.hw_trig, dh_in_lds=args.dh_in_lds)
+    eng.use_torch_stream()                                      # engine launches and torch/RCCL share one ordering
+    returns = eng.device_tensor(m.lib.F_TOTAL_REWARD)
+    L = args.episode_len
+
+    state = {"step": 0, "episode": 0, "gathered": None}
+    eng.reset_random(args.seed, 0)
+
+    def run_steps(count, kernel_ms=None):
+        """`count` env steps; episode boundary every L steps (gather returns over ranks, reset all)."""
+        done = 0
+        while done < count:
+            seg = min(count - done, L - state["step"] % L)
+            if kernel_ms is not None:
+                eng.timer_start()
+            eng.rollout(seg, args.seed, state["step"])
+            if kernel_ms is not None:
+                kernel_ms.append((eng.timer_stop(), seg))
+            state["step"] += seg
+            done += seg
+            if state["step"] % L == 0:
+                state["gathered"] = D.gather_returns(returns, n_total)      # RCCL all-gather (identity at N=1)
+                state["episode"] += 1
+                eng.reset_random(args.seed, state["episode"])
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    run_steps(args.warmup)
+    fence()
+    kernel_ms = []
+    t0 = time.perf_counter()
+    run_steps(args.steps, kernel_ms)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # sanity on what was computed (not timed): returns are small integers, something happened
+    tr = eng.total_reward()
+    assert np.isfinite(tr).all() and np.all(tr == np.round(tr))
+    if state["gathered"] is not None:
+        assert state["gathered"].numel() == n_total
+
+    if rank == 0:
+        bpe = algorithmic_bytes_per_env_step(args.dof, args.targets)
+        launches = sum(s for _, s in kernel_ms)
+        avg_kernel_s = sum(ms for ms, _ in kernel_ms) / launches / 1e3
+        achieved = bpe * n_local / avg_kernel_s / 1e9
+        workload = f"{n_local} arms/GPU x {world} GPU, {args.dof}-DoF DH chain, K={args.targets} targets, " \
+                   f"25 sub-steps, random integer-degree actions drawn in-kernel, episode {L} steps"
+        out = {
+            "metric": METRIC, "value": n_total * args.steps / elapsed, "unit": "env-steps/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": workload, "envs_per_gpu": n_local, "envs_total": n_total, "dof": args.dof,
+                       "targets": args.targets, "substeps": 25, "episode_len": L,
+                       "collective": "RCCL all-gather of returns per episode" if world > 1 else "none (1 GPU)",
+                       "kernel_variant": "hw_trig" if args.hw_trig else ("dh_in_lds" if args.dh_in_lds else "default")},
+            "roofline": {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": load_traffic(f"d{args.dof}_k{args.targets}_n{n_local}"),
+                "kernel": f"step_kernel<{args.dof}, sample, {'1' if args.hw_trig else ('2' if args.dh_in_lds else '0')}>",
+                "bytes_per_env_step": bpe, "avg_kernel_us": avg_kernel_s * 1e6,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(table, args.targets)
+        print(json.dumps(out), flush=True)
+
+    eng.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

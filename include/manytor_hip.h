@@ -1,0 +1,177 @@
+/*
+ * manytor_hip.h -- C ABI of libmanytor_hip.so (gfx950 / MI355X).
+ *
+ * Batched manipulator-environment step engine: N lock-stepped arms per handle,
+ * state resident in HBM as struct-of-arrays, one HIP launch per step.
+ *
+ * The reference (victorkich/ManyTor, manytor.py) has no FFI boundary: its
+ * boundary is the Python class surface of `Environment` / `Multienv`.  Each entry
+ * point below names the reference interface it replaces (file:line in the
+ * reference checkout) -- the Python host code in manytor_amd/ binds them with
+ * ctypes; INTEGRATION.md shows the stub.
+ *
+ * Conventions
+ *   - every function returns an mt_status (0 = ok, < 0 = error); the message of
+ *     the last error is available through mt_last_error().
+ *   - plain pointers and sizes only; no C++ / torch types.
+ *   - a handle owns one device, one HIP stream (replaceable with
+ *     mt_set_stream) and all of its device buffers.  A handle is not
+ *     re-entrant; different handles may be used from different threads.
+ *   - launches are asynchronous on the handle's stream; mt_sync() or any
+ *     host-destination mt_get() synchronises.
+ *   - angles are DEGREES (manytor.py:39), lengths are the DH table's units.
+ *   - "env-major" = the reference's array shapes with a leading env axis, e.g.
+ *     points (N, K, 3), obs (N, 3K).  "SoA" = the resident device layout, one
+ *     row of length `ld` (>= N, multiple of 256) per scalar field component,
+ *     e.g. points row (3*k + axis).
+ */
+#ifndef MANYTOR_HIP_H
+#define MANYTOR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#define MT_API __attribute__((visibility("default")))
+#else
+#define MT_API
+#endif
+
+#define MT_VERSION 100          /* major*10000 + minor*100 + patch */
+#define MT_MAX_DOF 8
+#define MT_MAX_TARGETS 32
+
+typedef struct mt_engine* mt_handle;
+
+typedef enum mt_status {
+  MT_OK = 0,
+  MT_ERR_INVALID_ARG = -1,
+  MT_ERR_HIP = -2,              /* a HIP runtime call failed; see mt_last_error */
+  MT_ERR_NO_DEVICE = -3,
+  MT_ERR_ALLOC = -4,
+  MT_ERR_STATE = -5,            /* call order violated (e.g. step before reset) */
+  MT_ERR_UNSUPPORTED = -6
+} mt_status;
+
+/* Fields of the resident state (mt_get / mt_set / mt_device_ptr). */
+typedef enum mt_field {
+  MT_F_ACTIONS = 0,       /* f32  env-major (N, D)      SoA rows: D        staged action, degrees            */
+  MT_F_GOALS = 1,         /* f32  (N, D)                rows: D            manytor.py:133 `goals`            */
+  MT_F_POINTS = 2,        /* f32  (N, K, 3)             rows: 3K           manytor.py:137 `points`           */
+  MT_F_ALIVE = 3,         /* u8   (N, K) via mt_get; device: u32 bitmask per env (bit p = target p alive)    */
+  MT_F_OBS = 4,           /* f32  (N, 3K)               rows: 3K           obs2 of the last step / observe   */
+  MT_F_REWARD = 5,        /* i32  (N,)                                      reward of the last step           */
+  MT_F_DONE = 6,          /* u8   (N,)                                      done of the last step             */
+  MT_F_DONE_BITS = 7,     /* u64  (ceil(N/64),) one wavefront ballot per 64 envs, bit l = env 64*w + l       */
+  MT_F_EE = 8,            /* f32  (N, 3)                rows: 3            end effector = joints_coordinates[-1] */
+  MT_F_TOTAL_REWARD = 9,  /* f32  (N,)                                      manytor.py:138 `total_reward`     */
+  MT_F_JOINTS = 10,       /* f32  (N, D, 3) computed on demand from goals (manytor.py:188-189); mt_get only  */
+  MT_F_COUNT = 11
+} mt_field;
+
+typedef enum mt_dtype { MT_F32 = 0, MT_F64 = 1, MT_I32 = 2, MT_I64 = 3, MT_U8 = 4, MT_U32 = 5, MT_U64 = 6 } mt_dtype;
+
+typedef enum mt_layout { MT_ENV_MAJOR = 0, MT_SOA = 1 } mt_layout;
+
+/* Engine flags (mt_config.flags). Defaults (0) reproduce the reference. */
+#define MT_FLAG_TERMINATE_ON_GROUND 0x1u /* done |= ground hit (README.md:44 intent; NOT what manytor.py:170 does) */
+#define MT_FLAG_HW_TRIG 0x2u             /* v_sin/v_cos for the intermediate sub-steps (ground flag only)          */
+#define MT_FLAG_DH_IN_LDS 0x4u           /* stage the DH constants in LDS instead of SGPRs (measured variant)     */
+
+/* Constructor arguments.  Replaces Environment.__init__/Multienv.__init__
+ * (manytor.py:130-139, :77-82) plus the literals the reference hard-codes:
+ * DH table manytor.py:42-48, substeps :178, pickup tolerance :162, radius :231. */
+typedef struct mt_config {
+  int32_t struct_size;          /* = sizeof(mt_config), checked                                  */
+  int32_t device;               /* HIP device ordinal                                            */
+  int64_t n_envs;               /* envs owned by this handle (this rank's shard)                 */
+  int64_t env_id_base;          /* global id of local env 0: keys the device RNG so results do   */
+                                /* not depend on the shard count                                 */
+  int32_t dof;                  /* 2..MT_MAX_DOF joints                                          */
+  int32_t n_targets;            /* 1..MT_MAX_TARGETS  (obj_number)                               */
+  int32_t substeps;             /* >= 2; reference 25                                            */
+  uint32_t flags;               /* MT_FLAG_*                                                     */
+  float pickup_tol;             /* reference 8.0                                                 */
+  float radius;                 /* target hemisphere radius, reference 51.3                      */
+  float dh_table[MT_MAX_DOF * 4]; /* rows (a, alpha_rad, d, theta_offset_rad), manytor.py:42-48 */
+} mt_config;
+
+MT_API int mt_version(void);
+MT_API const char* mt_status_string(int status);
+/* Message of the last failing call on this handle (or, with h == NULL, of the
+ * last failing call on the calling thread that had no handle). */
+MT_API const char* mt_last_error(mt_handle h);
+MT_API int mt_device_count(int* count);
+
+/* Environment()/Multienv() constructors, manytor.py:130-139 / :77-82. */
+MT_API int mt_create(mt_handle* out, const mt_config* cfg);
+MT_API int mt_destroy(mt_handle h);
+/* Run on a caller-owned hipStream_t (e.g. torch's current stream); NULL restores the handle's own. */
+MT_API int mt_set_stream(mt_handle h, void* hip_stream);
+MT_API int mt_sync(mt_handle h);
+
+/* Environment.reset(), manytor.py:219-253, for all envs.
+ * mt_reset: targets supplied by the caller (parity mode: the host draws them from
+ * numpy's global RNG in the reference's order).  `points` is (N, K, 3) f32
+ * env-major or (3K, ld) SoA, in host or device memory.
+ * mt_reset_random: targets rejection-sampled on the device (Philox-4x32-10 keyed by
+ * seed / global env id / episode), same law as manytor.py:229-239. */
+MT_API int mt_reset(mt_handle h, const float* points, int layout, int is_device);
+MT_API int mt_reset_random(mt_handle h, uint64_t seed, uint32_t episode);
+/* Re-arm only the envs whose done byte is set (new targets from the device RNG,
+ * zero pose, zero return).  Not in the reference (the caller resets everything,
+ * test_multi.py:34); SURVEY.md 8(f) rank 1. */
+MT_API int mt_reset_done(mt_handle h, uint64_t seed, uint32_t episode);
+
+/* Stage the action of the next mt_step: (N, D) env-major or (D, ld) SoA, degrees,
+ * any of f32/f64/i32/i64 (Environment.action_sample returns np.int64, manytor.py:216). */
+MT_API int mt_set_actions(mt_handle h, const void* actions, int dtype, int layout, int is_device);
+/* Environment.action_sample(), manytor.py:215-217, for all envs on the device:
+ * integer degrees uniform in [-180, 180), written to the action buffer. */
+MT_API int mt_sample_actions(mt_handle h, uint64_t seed, uint32_t step_idx);
+
+/* Environment.step() = get_observations() side effect + action() + return
+ * accumulation + is_done(), manytor.py:255-260, :175-213, for all envs, one launch. */
+MT_API int mt_step(mt_handle h);
+/* The same with the action drawn in-kernel (bit-identical to mt_sample_actions
+ * followed by mt_step); the drawn action is also written to the action buffer. */
+MT_API int mt_step_random(mt_handle h, uint64_t seed, uint32_t step_idx);
+/* n_steps x mt_step_random with step indices step_idx0, step_idx0+1, ... (the
+ * inner loop of test_multi.py:19-21). */
+MT_API int mt_rollout(mt_handle h, int n_steps, uint64_t seed, uint32_t step_idx0);
+
+/* Environment.get_observations(), manytor.py:141-153, at the current pose (also
+ * zeroes the coordinates of dead targets, :148).  Result in MT_F_OBS. */
+MT_API int mt_observe(mt_handle h);
+/* Environment.is_done(), manytor.py:155-173, at the current pose. Result in MT_F_DONE. */
+MT_API int mt_check_done(mt_handle h);
+
+/* Copy a field out in the reference's env-major shape (see mt_field) to host
+ * (is_device = 0, synchronises) or device memory.  dst_bytes must match. */
+MT_API int mt_get(mt_handle h, int field, void* dst, int64_t dst_bytes, int is_device);
+/* Overwrite GOALS / POINTS / ALIVE(u8 N,K) / TOTAL_REWARD from host env-major
+ * arrays (attribute assignment on the reference objects, e.g. manytor.py:243). */
+MT_API int mt_set(mt_handle h, int field, const void* src, int64_t src_bytes);
+/* Raw resident buffer: pointer to row 0, number of rows, row stride in elements and element dtype. */
+MT_API int mt_device_ptr(mt_handle h, int field, void** ptr, int64_t* rows, int64_t* ld, int* dtype);
+
+/* HIP-event timer on the handle's stream (wall-clock of test_multi.py:16-18, device side). */
+MT_API int mt_timer_start(mt_handle h);
+MT_API int mt_timer_stop(mt_handle h, float* elapsed_ms);
+
+/* Stateless kinematics helpers = the module functions of the reference.
+ * mt_fk_batch: fk(mode, goals), manytor.py:35-53 -> 4x4 row-major per pose; with
+ * dof = mode = 1, angles_in_radians = 1 it is dh(a, alfa, d, theta), manytor.py:25-32.
+ * mt_r_theta_batch: r_theta(v1, v2), manytor.py:17-22 -> (r_deg, theta_deg).
+ * Host pointers in, host pointers out; run on `device`. */
+MT_API int mt_fk_batch(int device, const float* dh_table, int dof, int mode, const float* angles, int angles_in_radians,
+                int64_t n, float* out_mat16);
+MT_API int mt_r_theta_batch(int device, const float* v1, const float* v2, int64_t n, float* out_r_theta);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MANYTOR_HIP_H */

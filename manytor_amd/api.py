@@ -1,0 +1,313 @@
+"""The gym-style surface of the reference (``import manytor as tor``) on the HIP engine.
+
+Same names, defaults and return arity as /root/reference/manytor.py:
+``Environment`` (:125-283), ``Multienv`` (:72-122), ``dh`` / ``fk`` / ``r_theta``
+(:17-53), ``HOST`` / ``PORT`` (:9-10).  Every number is computed on the GPU by
+libmanytor_hip.so; there is no CPU path (constructing an env without a GPU raises).
+
+Two RNG modes:
+  rng="numpy"  (default) targets and sampled actions come from numpy's global
+               RandomState in the reference's draw order -> ``np.random.seed(s)``
+               reproduces a reference run bit-for-bit on the inputs.
+  rng="device" Philox-4x32-10 on the GPU keyed by (seed, global env id, episode /
+               step): nothing crosses PCIe; results independent of sharding.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+from . import _lib as L
+from . import rng as _rng
+from .engine import REF_DH_TABLE, StepEngine, fk_batch, r_theta_batch
+
+HOST = "localhost"     # manytor.py:9   (viewer address; rendering itself is out of scope here)
+PORT = 5001            # manytor.py:10
+
+_MATERIALIZE_LIMIT = 4096   # up to this many envs, step()/reset() return real Python lists like the reference
+
+
+# ---- module functions (manytor.py:17-53) --------------------------------------------------------
+def r_theta(v1, v2):
+    """manytor.py:17-22 -> (r_deg, theta_deg)."""
+    out = r_theta_batch(np.asarray(v1, dtype=np.float64)[:3], np.asarray(v2, dtype=np.float64)[:3])[0]
+    return float(out[0]), float(out[1])
+
+
+def dh(a, alfa, d, theta):
+    """manytor.py:25-32 -> 4x4 homogeneous transform (theta, alfa in radians)."""
+    return fk_batch(1, [[theta]], dh_table=[(a, alfa, d, 0.0)], radians=True)[0].astype(np.float64)
+
+
+def fk(mode, goals):
+    """manytor.py:35-53 -> 4x4 transform of the first `mode` joints of the reference arm (goals in degrees)."""
+    return fk_batch(mode, [list(goals)[:4]], dh_table=REF_DH_TABLE)[0].astype(np.float64)
+
+
+# ---- sequence proxies -----------------------------------------------------------------------
+class BatchView:
+    """Read-only sequence over the env axis of a device field, for N too large to turn into Python
+    objects (never materialise 1 M objects).  ``len``/indexing/iteration behave like the
+    reference's lists; ``.numpy()`` is one D2H copy; ``.torch()`` is a zero-copy device view.
+    Deliberately no ``__eq__``: ``done == True`` is False, as it is for the reference's list
+    (test_multi.py:22)."""
+
+    def __init__(self, engine, field, post=None):
+        self._e, self._f, self._post = engine, field, post
+        self._host = None
+        self._ver = engine.version
+
+    def numpy(self):
+        if self._host is None:
+            if self._ver != self._e.version:
+                raise RuntimeError("stale BatchView: the engine has stepped since this result was returned")
+            a = self._e.get(self._f)
+            self._host = self._post(a) if self._post else a
+        return self._host
+
+    def torch(self):
+        t = self._e.device_tensor(self._f)
+        return t if t.dim() == 1 else t.T
+
+    def __array__(self, dtype=None, copy=None):
+        a = self.numpy()
+        return a.astype(dtype) if dtype is not None else a
+
+    def __len__(self):
+        return self._e.n_envs
+
+    def __getitem__(self, i):
+        return self.numpy()[i]
+
+    def __iter__(self):
+        return iter(self.numpy())
+
+
+class _EnvView:
+    """``multienv.environment[i]``: attribute access to one env of the batch (manytor.py:131-139)."""
+
+    def __init__(self, owner, index):
+        self._o, self.id = owner, index
+
+    obj_number = property(lambda s: s._o.obj_number)
+    rendering = property(lambda s: s._o.rendering)
+    goals = property(lambda s: s._o._cached(L.F_GOALS)[s.id].astype(np.float64))
+    alives = property(lambda s: s._o._cached(L.F_ALIVE)[s.id].astype(bool))
+    points = property(lambda s: s._o._cached(L.F_POINTS)[s.id].astype(np.float64))
+    joints_coordinates = property(lambda s: s._o._cached(L.F_JOINTS)[s.id].astype(np.float64))
+    total_reward = property(lambda s: float(s._o._cached(L.F_TOTAL_REWARD)[s.id]))
+
+    def get_observations(self):
+        self._o._engine.observe()
+        return self._o._cached(L.F_OBS)[self.id].astype(np.float64)
+
+    get_obs = get_observations
+
+    def is_done(self):
+        return not self.alives.any()
+
+
+class _EnvList:
+    def __init__(self, owner):
+        self._o = owner
+
+    def __len__(self):
+        return self._o.env_number
+
+    def __getitem__(self, i):
+        n = self._o.env_number
+        if isinstance(i, slice):
+            return [_EnvView(self._o, j) for j in range(*i.indices(n))]
+        if i < 0:
+            i += n
+        if not 0 <= i < n:
+            raise IndexError("list index out of range")
+        return _EnvView(self._o, i)
+
+    def __iter__(self):
+        return (_EnvView(self._o, j) for j in range(self._o.env_number))
+
+
+# ---- Multienv (manytor.py:72-122) --------------------------------------------------------------
+class Multienv:
+    """``Multienv(env_shape=(1, 2), obj_number=5)``: env_shape[0]*env_shape[1] arms stepped in one launch."""
+
+    def __init__(self, env_shape=(1, 2), obj_number=5, *, rng="numpy", seed=0x5EED, device=0, env_id_base=0,
+                 dh_table=REF_DH_TABLE, substeps=25, pickup_tol=8.0, radius=51.3, terminate_on_ground=False,
+                 materialize="auto", **engine_kwargs):
+        if rng not in ("numpy", "device"):
+            raise ValueError("rng must be 'numpy' or 'device'")
+        self.env_shape = env_shape
+        self.env_number = env_shape[0] * env_shape[1]
+        self.obj_number = obj_number
+        self.rendering = False
+        self.rng = rng
+        self.seed = int(seed)
+        self.radius = radius
+        self._episode = 0
+        self._step_idx = 0
+        self._engine = StepEngine(self.env_number, obj_number, dh_table=dh_table, substeps=substeps,
+                                  pickup_tol=pickup_tol, radius=radius, device=device, env_id_base=env_id_base,
+                                  terminate_on_ground=terminate_on_ground, **engine_kwargs)
+        self._materialize = (self.env_number <= _MATERIALIZE_LIMIT) if materialize == "auto" else bool(materialize)
+        self._cache = {}
+        self.environment = _EnvList(self)
+
+    @property
+    def engine(self) -> StepEngine:
+        return self._engine
+
+    def _cached(self, field):
+        ver = self._engine.version
+        hit = self._cache.get(field)
+        if hit is None or hit[0] != ver:
+            hit = (ver, self._engine.get(field))
+            self._cache[field] = hit
+        return hit[1]
+
+    def render(self, stop_render=False):
+        """manytor.py:84-104.  The vispy/UDP viewer is out of scope; only the flag is kept so that
+        the control flow of test_multi.py:25-28 is unchanged."""
+        self.rendering = not stop_render
+
+    def reset(self, returnable=False):
+        """manytor.py:106-109."""
+        if self.rng == "numpy":
+            self._engine.reset(_rng.draw_targets(self.env_number, self.obj_number, self.radius))
+        else:
+            self._engine.reset_random(self.seed, self._episode)
+        self._episode += 1
+        if returnable:
+            self._engine.observe()
+            if self._materialize:
+                return [row.astype(np.float64) for row in self._engine.obs()]
+            return BatchView(self._engine, L.F_OBS)
+
+    def action_sample(self):
+        """manytor.py:111-113.  numpy mode: list of per-env lists of np.int64 (like the reference) for small N,
+        an (N, D) int64 array otherwise.  device mode: draws into the device action buffer and returns None-like
+        token ``self.DEVICE_ACTIONS``; pass it to step()."""
+        if self.rng == "numpy":
+            a = _rng.draw_actions(self.env_number, self._engine.dof)
+            return [list(row) for row in a] if self._materialize else a
+        self._engine.sample_actions(self.seed, self._step_idx)
+        return DEVICE_ACTIONS
+
+    def step(self, action):
+        """manytor.py:115-122 -> (obs2_list, reward_list, done_list)."""
+        if action is DEVICE_ACTIONS:
+            self._engine.step()
+        else:
+            self._engine.step(action)
+        self._step_idx += 1
+        if self._materialize:
+            e = self._engine
+            return ([row.astype(np.float64) for row in e.obs()], [int(r) for r in e.reward()],
+                    [bool(d) for d in e.done()])
+        e = self._engine
+        return (BatchView(e, L.F_OBS), BatchView(e, L.F_REWARD), BatchView(e, L.F_DONE, post=lambda a: a.astype(bool)))
+
+    def close(self):
+        self._engine.close()
+
+
+class _DeviceActions:
+    """Token returned by action_sample() in device mode: 'the actions already in the device buffer'."""
+
+    def __repr__(self):
+        return "<actions resident on the device>"
+
+
+DEVICE_ACTIONS = _DeviceActions()
+Multienv.DEVICE_ACTIONS = DEVICE_ACTIONS
+
+
+# ---- Environment (manytor.py:125-283) ---------------------------------------------------------
+class Environment:
+    """``Environment(obj_number=10, index=0)``: one arm = a batch of one on the same engine."""
+
+    def __init__(self, obj_number=10, index=0, *, rng="numpy", seed=0x5EED, device=0, dh_table=REF_DH_TABLE,
+                 substeps=25, pickup_tol=8.0, radius=51.3, terminate_on_ground=False):
+        if rng not in ("numpy", "device"):
+            raise ValueError("rng must be 'numpy' or 'device'")
+        self.id = index
+        self.obj_number = obj_number
+        self.rendering = False
+        self.rng = rng
+        self.seed = int(seed)
+        self.radius = radius
+        self._episode = 0
+        self._step_idx = 0
+        self._engine = StepEngine(1, obj_number, dh_table=dh_table, substeps=substeps, pickup_tol=pickup_tol,
+                                  radius=radius, device=device, env_id_base=index,
+                                  terminate_on_ground=terminate_on_ground)
+        # the reference constructor leaves points/joints empty until reset() (manytor.py:136-137);
+        # arm the device state at the zero pose so attribute reads are defined
+        self._engine.reset(np.zeros((1, obj_number, 3), dtype=np.float32))
+
+    # state attributes (manytor.py:131-139); reads are D2H copies, writes are H2D
+    goals = property(lambda s: s._engine.goals()[0].astype(np.float64),
+                     lambda s, v: s._engine.set(L.F_GOALS, np.asarray(v, dtype=np.float32).reshape(1, -1)))
+    alives = property(lambda s: s._engine.alives()[0],
+                      lambda s, v: s._engine.set(L.F_ALIVE, np.asarray(v, dtype=np.uint8).reshape(1, -1)))
+    points = property(lambda s: s._engine.points()[0].astype(np.float64),
+                      lambda s, v: s._engine.set(L.F_POINTS, np.asarray(v, dtype=np.float32).reshape(1, -1, 3)))
+    total_reward = property(lambda s: float(s._engine.total_reward()[0]),
+                            lambda s, v: s._engine.set(L.F_TOTAL_REWARD, np.asarray([v], dtype=np.float32)))
+    joints_coordinates = property(lambda s: s._engine.joints_coordinates()[0].astype(np.float64))
+
+    @property
+    def engine(self) -> StepEngine:
+        return self._engine
+
+    def get_observations(self):
+        """manytor.py:141-153."""
+        self._engine.observe()
+        return self._engine.obs()[0].astype(np.float64)
+
+    get_obs = get_observations      # the name BASELINE.json's north_star uses
+
+    def is_done(self):
+        """manytor.py:155-173."""
+        self._engine.check_done()
+        return bool(self._engine.done()[0])
+
+    def action(self, action, obs=None):
+        """manytor.py:175-213 -> (reward, obs2).  Like the reference it does not add to total_reward;
+        the fused step kernel does, so the increment is taken back out."""
+        before = self._engine.total_reward()
+        self._engine.step(np.asarray(action, dtype=np.float64).reshape(1, -1))
+        self._engine.set(L.F_TOTAL_REWARD, before)
+        return int(self._engine.reward()[0]), self._engine.obs()[0].astype(np.float64)
+
+    def action_sample(self):
+        """manytor.py:215-217 -> list of D integer degrees in [-180, 180)."""
+        if self.rng == "numpy":
+            return list(_rng.draw_actions(1, self._engine.dof)[0])
+        self._engine.sample_actions(self.seed, self._step_idx)
+        return [np.int64(v) for v in self._engine.actions()[0]]
+
+    def reset(self, returnable=False):
+        """manytor.py:219-253."""
+        if self.rng == "numpy":
+            self._engine.reset(_rng.draw_targets(1, self.obj_number, self.radius))
+        else:
+            self._engine.reset_random(self.seed, self._episode)
+        self._episode += 1
+        if returnable:
+            return self.get_observations()
+
+    def step(self, action):
+        """manytor.py:255-260 -> (obs2, reward, done)."""
+        self._engine.step(np.asarray(action, dtype=np.float64).reshape(1, -1))
+        self._step_idx += 1
+        e = self._engine
+        return e.obs()[0].astype(np.float64), int(e.reward()[0]), bool(e.done()[0])
+
+    def render(self, stop_render=False, multienv=False):
+        """manytor.py:262-283: viewer out of scope, flag only."""
+        self.rendering = not stop_render
+
+    def close(self):
+        self._engine.close()

@@ -1,0 +1,663 @@
+// libmanytor_hip.so -- host side of the C ABI declared in include/manytor_hip.h.
+//
+// Owns the device arena (SoA rows in HBM), the stream, and the launch logic.
+// No arithmetic of the step path happens here: everything the reference
+// computes in manytor.py:17-53,141-260 runs in the kernels of kernels.h.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "kernels.h"
+
+using namespace mt;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+struct Buf {
+  void* p = nullptr;
+  size_t bytes = 0;
+};
+
+}  // namespace
+
+struct mt_engine {
+  mt_config cfg{};
+  int64_t n = 0, ld = 0;
+  int D = 0, K = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  void* arena = nullptr;
+  size_t arena_bytes = 0;
+  void* staging = nullptr;
+  size_t staging_bytes = 0;
+  StepArgs args{};
+  bool is_reset = false;
+  int variant = 0;
+  std::string err;
+};
+
+namespace {
+
+int fail(mt_handle h, int code, const std::string& msg) {
+  if (h)
+    h->err = msg;
+  else
+    g_last_error = msg;
+  return code;
+}
+
+#define MT_HIP(h, call)                                                                        \
+  do {                                                                                         \
+    hipError_t e__ = (call);                                                                   \
+    if (e__ != hipSuccess)                                                                     \
+      return fail(h, MT_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e__));          \
+  } while (0)
+
+#define MT_REQUIRE(h, cond, msg) \
+  do {                           \
+    if (!(cond)) return fail(h, MT_ERR_INVALID_ARG, msg); \
+  } while (0)
+
+inline dim3 grid_for(int64_t n) { return dim3((unsigned)((n + kBlock - 1) / kBlock)); }
+
+DhConst make_dh(const float* table, int dof) {
+  DhConst t{};
+  for (int j = 0; j < MT_MAX_DOF; ++j) {
+    t.ca[j] = 1.f;
+  }
+  for (int j = 0; j < dof; ++j) {
+    const double a = table[4 * j + 0], alpha = table[4 * j + 1], d = table[4 * j + 2], off = table[4 * j + 3];
+    t.a[j] = (float)a;
+    t.d[j] = (float)d;
+    // snap multiples of pi/2 so that e.g. cos(pi/2) is 0, not 6e-17 (the reference's residue)
+    double sa = std::sin(alpha), ca = std::cos(alpha);
+    if (std::fabs(sa) < 1e-7) sa = 0.0;
+    if (std::fabs(ca) < 1e-7) ca = 0.0;
+    t.sa[j] = (float)sa;
+    t.ca[j] = (float)ca;
+    t.off_deg[j] = (float)(off * 180.0 / M_PI);
+  }
+  return t;
+}
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+int ensure_staging(mt_handle h, size_t bytes) {
+  if (h->staging_bytes >= bytes) return MT_OK;
+  if (h->staging) {
+    MT_HIP(h, hipStreamSynchronize(h->stream));
+    MT_HIP(h, hipFree(h->staging));
+    h->staging = nullptr;
+    h->staging_bytes = 0;
+  }
+  if (hipMalloc(&h->staging, bytes) != hipSuccess) return fail(h, MT_ERR_ALLOC, "hipMalloc(staging) failed");
+  h->staging_bytes = bytes;
+  return MT_OK;
+}
+
+// ---- kernel dispatch on the compile-time joint count -------------------------------------------
+template <int D>
+void launch_step_d(mt_handle h, bool sample) {
+  const dim3 g = grid_for(h->n), b(kBlock);
+  const int v = h->variant;
+  if (sample) {
+    if (v == 1)
+      hipLaunchKernelGGL((step_kernel<D, true, 1>), g, b, 0, h->stream, h->args);
+    else if (v == 2)
+      hipLaunchKernelGGL((step_kernel<D, true, 2>), g, b, 0, h->stream, h->args);
+    else
+      hipLaunchKernelGGL((step_kernel<D, true, 0>), g, b, 0, h->stream, h->args);
+  } else {
+    if (v == 1)
+      hipLaunchKernelGGL((step_kernel<D, false, 1>), g, b, 0, h->stream, h->args);
+    else if (v == 2)
+      hipLaunchKernelGGL((step_kernel<D, false, 2>), g, b, 0, h->stream, h->args);
+    else
+      hipLaunchKernelGGL((step_kernel<D, false, 0>), g, b, 0, h->stream, h->args);
+  }
+}
+
+#define MT_DISPATCH_D(D_, FN, ...)   \
+  switch (D_) {                      \
+    case 2: FN<2>(__VA_ARGS__); break; \
+    case 3: FN<3>(__VA_ARGS__); break; \
+    case 4: FN<4>(__VA_ARGS__); break; \
+    case 5: FN<5>(__VA_ARGS__); break; \
+    case 6: FN<6>(__VA_ARGS__); break; \
+    case 7: FN<7>(__VA_ARGS__); break; \
+    case 8: FN<8>(__VA_ARGS__); break; \
+    default: break;                  \
+  }
+
+template <int D>
+void launch_reset_d(mt_handle h, int mode) {  // 0 given points, 1 random, 2 random only-done
+  const dim3 g = grid_for(h->n), b(kBlock);
+  if (mode == 0)
+    hipLaunchKernelGGL((reset_kernel<D, false, false>), g, b, 0, h->stream, h->args, h->cfg.radius);
+  else if (mode == 1)
+    hipLaunchKernelGGL((reset_kernel<D, true, false>), g, b, 0, h->stream, h->args, h->cfg.radius);
+  else
+    hipLaunchKernelGGL((reset_kernel<D, true, true>), g, b, 0, h->stream, h->args, h->cfg.radius);
+}
+
+template <int D>
+void launch_observe_d(mt_handle h) {
+  hipLaunchKernelGGL((observe_kernel<D>), grid_for(h->n), dim3(kBlock), 0, h->stream, h->args);
+}
+template <int D>
+void launch_check_done_d(mt_handle h) {
+  hipLaunchKernelGGL((check_done_kernel<D>), grid_for(h->n), dim3(kBlock), 0, h->stream, h->args);
+}
+template <int D>
+void launch_joints_d(mt_handle h, float* out) {
+  hipLaunchKernelGGL((joints_kernel<D>), grid_for(h->n), dim3(kBlock), 0, h->stream, h->args, out);
+}
+
+int check_launch(mt_handle h, const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(h, MT_ERR_HIP, std::string(what) + " launch: " + hipGetErrorString(e));
+  return MT_OK;
+}
+
+struct FieldInfo {
+  void* ptr;
+  int rows;      // SoA rows
+  int dtype;     // element dtype of the resident buffer
+  size_t esize;  // element size
+};
+
+int field_info(mt_handle h, int field, FieldInfo* fi) {
+  const StepArgs& a = h->args;
+  switch (field) {
+    case MT_F_ACTIONS: *fi = {a.actions, h->D, MT_F32, 4}; return MT_OK;
+    case MT_F_GOALS: *fi = {a.goals, h->D, MT_F32, 4}; return MT_OK;
+    case MT_F_POINTS: *fi = {a.points, 3 * h->K, MT_F32, 4}; return MT_OK;
+    case MT_F_ALIVE: *fi = {a.alive, 1, MT_U32, 4}; return MT_OK;
+    case MT_F_OBS: *fi = {a.obs, 3 * h->K, MT_F32, 4}; return MT_OK;
+    case MT_F_REWARD: *fi = {a.reward, 1, MT_I32, 4}; return MT_OK;
+    case MT_F_DONE: *fi = {a.done, 1, MT_U8, 1}; return MT_OK;
+    case MT_F_DONE_BITS: *fi = {a.done_bits, 1, MT_U64, 8}; return MT_OK;
+    case MT_F_EE: *fi = {a.ee, 3, MT_F32, 4}; return MT_OK;
+    case MT_F_TOTAL_REWARD: *fi = {a.total_reward, 1, MT_F32, 4}; return MT_OK;
+    default: return fail(h, MT_ERR_INVALID_ARG, "unknown or non-resident field");
+  }
+}
+
+}  // namespace
+
+// =================================================================================================
+extern "C" {
+
+int mt_version(void) { return MT_VERSION; }
+
+const char* mt_status_string(int status) {
+  switch (status) {
+    case MT_OK: return "ok";
+    case MT_ERR_INVALID_ARG: return "invalid argument";
+    case MT_ERR_HIP: return "HIP runtime error";
+    case MT_ERR_NO_DEVICE: return "no usable HIP device";
+    case MT_ERR_ALLOC: return "device allocation failed";
+    case MT_ERR_STATE: return "invalid call order";
+    case MT_ERR_UNSUPPORTED: return "unsupported";
+    default: return "unknown status";
+  }
+}
+
+const char* mt_last_error(mt_handle h) { return h ? h->err.c_str() : g_last_error.c_str(); }
+
+int mt_device_count(int* count) {
+  MT_REQUIRE(nullptr, count != nullptr, "count is NULL");
+  int c = 0;
+  hipError_t e = hipGetDeviceCount(&c);
+  if (e != hipSuccess) {
+    *count = 0;
+    (void)hipGetLastError();
+    return fail(nullptr, MT_ERR_NO_DEVICE, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+  }
+  *count = c;
+  return MT_OK;
+}
+
+int mt_create(mt_handle* out, const mt_config* cfg) {
+  MT_REQUIRE(nullptr, out != nullptr && cfg != nullptr, "out/cfg is NULL");
+  *out = nullptr;
+  MT_REQUIRE(nullptr, cfg->struct_size == (int32_t)sizeof(mt_config), "mt_config.struct_size mismatch");
+  MT_REQUIRE(nullptr, cfg->n_envs >= 1, "n_envs must be >= 1");
+  MT_REQUIRE(nullptr, cfg->dof >= 2 && cfg->dof <= MT_MAX_DOF, "dof must be in 2..8");
+  MT_REQUIRE(nullptr, cfg->n_targets >= 1 && cfg->n_targets <= MT_MAX_TARGETS, "n_targets must be in 1..32");
+  MT_REQUIRE(nullptr, cfg->substeps >= 2, "substeps must be >= 2");
+  MT_REQUIRE(nullptr, cfg->pickup_tol >= 0.f && cfg->radius > 0.f, "pickup_tol/radius out of range");
+  MT_REQUIRE(nullptr, cfg->env_id_base >= 0, "env_id_base must be >= 0");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    (void)hipGetLastError();
+    return fail(nullptr, MT_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU path)");
+  }
+  MT_REQUIRE(nullptr, cfg->device >= 0 && cfg->device < ndev, "device ordinal out of range");
+
+  mt_engine* h = new (std::nothrow) mt_engine();
+  if (!h) return fail(nullptr, MT_ERR_ALLOC, "out of host memory");
+  h->cfg = *cfg;
+  h->n = cfg->n_envs;
+  h->ld = (int64_t)align_up((size_t)cfg->n_envs, 256);
+  h->D = cfg->dof;
+  h->K = cfg->n_targets;
+  h->variant = (cfg->flags & MT_FLAG_DH_IN_LDS) ? 2 : ((cfg->flags & MT_FLAG_HW_TRIG) ? 1 : 0);
+
+  auto bail = [&](int code, const std::string& msg) {
+    g_last_error = msg;
+    if (h->arena) (void)hipFree(h->arena);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+    delete h;
+    return code;
+  };
+#define MT_HIP_C(call)                                                                       \
+  do {                                                                                       \
+    hipError_t e__ = (call);                                                                 \
+    if (e__ != hipSuccess) return bail(MT_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e__)); \
+  } while (0)
+
+  MT_HIP_C(hipSetDevice(cfg->device));
+  MT_HIP_C(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+  h->stream = h->own_stream;
+  MT_HIP_C(hipEventCreate(&h->ev0));
+  MT_HIP_C(hipEventCreate(&h->ev1));
+
+  // arena layout: every row block starts on a 1 KiB boundary
+  const size_t ld = (size_t)h->ld, D = (size_t)h->D, K = (size_t)h->K;
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    size_t o = off;
+    off = align_up(off + bytes, 1024);
+    return o;
+  };
+  const size_t o_act = take(D * ld * 4), o_goal = take(D * ld * 4), o_pts = take(3 * K * ld * 4),
+               o_obs = take(3 * K * ld * 4), o_alive = take(ld * 4), o_tot = take(ld * 4), o_rew = take(ld * 4),
+               o_done = take(ld), o_bits = take(ld / 64 * 8), o_ee = take(3 * ld * 4);
+  h->arena_bytes = off;
+  if (hipMalloc(&h->arena, h->arena_bytes) != hipSuccess) {
+    (void)hipGetLastError();
+    return bail(MT_ERR_ALLOC, "hipMalloc of the state arena failed (" + std::to_string(h->arena_bytes) + " bytes)");
+  }
+  MT_HIP_C(hipMemsetAsync(h->arena, 0, h->arena_bytes, h->stream));
+  char* base = (char*)h->arena;
+  StepArgs& a = h->args;
+  a.actions = (float*)(base + o_act);
+  a.goals = (float*)(base + o_goal);
+  a.points = (float*)(base + o_pts);
+  a.obs = (float*)(base + o_obs);
+  a.alive = (uint32_t*)(base + o_alive);
+  a.total_reward = (float*)(base + o_tot);
+  a.reward = (int32_t*)(base + o_rew);
+  a.done = (uint8_t*)(base + o_done);
+  a.done_bits = (unsigned long long*)(base + o_bits);
+  a.ee = (float*)(base + o_ee);
+  a.n = h->n;
+  a.ld = h->ld;
+  a.env_base = cfg->env_id_base;
+  a.K = h->K;
+  a.S = cfg->substeps;
+  a.tol = cfg->pickup_tol;
+  a.inv_sm1 = 1.0f / (float)(cfg->substeps - 1);
+  a.flags = cfg->flags;
+  a.dh = make_dh(cfg->dh_table, h->D);
+#undef MT_HIP_C
+  *out = h;
+  return MT_OK;
+}
+
+int mt_destroy(mt_handle h) {
+  if (!h) return MT_OK;
+  (void)hipSetDevice(h->cfg.device);
+  (void)hipStreamSynchronize(h->stream);
+  if (h->staging) (void)hipFree(h->staging);
+  if (h->arena) (void)hipFree(h->arena);
+  if (h->ev0) (void)hipEventDestroy(h->ev0);
+  if (h->ev1) (void)hipEventDestroy(h->ev1);
+  if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+  delete h;
+  return MT_OK;
+}
+
+int mt_set_stream(mt_handle h, void* hip_stream) {
+  MT_REQUIRE(nullptr, h != nullptr, "handle is NULL");
+  MT_HIP(h, hipStreamSynchronize(h->stream));
+  h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+  return MT_OK;
+}
+
+int mt_sync(mt_handle h) {
+  MT_REQUIRE(nullptr, h != nullptr, "handle is NULL");
+  MT_HIP(h, hipStreamSynchronize(h->stream));
+  return MT_OK;
+}
+
+// ---- reset ------------------------------------------------------------------------------------
+int mt_reset(mt_handle h, const float* points, int layout, int is_device) {
+  MT_REQUIRE(nullptr, h != nullptr, "handle is NULL");
+  MT_REQUIRE(h, points != nullptr, "points is NULL (use mt_reset_random for device-drawn targets)");
+  MT_REQUIRE(h, layout == MT_ENV_MAJOR || layout == MT_SOA, "bad layout");
+  MT_HIP(h, hipSetDevice(h->cfg.device));
+  const int rows = 3 * h->K;
+  if (layout == MT_SOA) {
+    const size_t bytes = (size_t)rows * h->ld * 4;
+    MT_HIP(h, hipMemcpyAsync(h->args.points, points, bytes, is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
+                             h->stream));
+  } else {
+    const size_t bytes = (size_t)rows * h->n * 4;
+    const float* src = points;
+    if (!is_device) {
+      int rc = ensure_staging(h, bytes);
+      if (rc) return rc;
+      MT_HIP(h, hipMemcpyAsync(h->staging, points, bytes, hipMemcpyHostToDevice, h->stream));
+      src = (const float*)h->staging;
+    }
+    hipLaunchKernelGGL((env_major_to_soa<float>), grid_for(h->n), dim3(kBlock), 0, h->stream, src, rows, h->n,
+                       h->args.points, h->ld);
+    int rc = check_launch(h, "env_major_to_soa");
+    if (rc) return rc;
+  }
+  MT_DISPATCH_D(h->D, launch_reset_d, h, 0);
+  int rc = check_launch(h, "reset_kernel");
+  if (rc) return rc;
+  if (!is_device) MT_HIP(h, hipStreamSynchronize(h->stream));  // the caller may free `points` on return
+  h->is_reset = true;
+  return MT_OK;
+}
+
+static int reset_random_impl(mt_handle h, uint64_t seed, uint32_t episode, int mode) {
+  MT_REQUIRE(nullptr, h != nullptr, "handle is NULL");
+  MT_HIP(h, hipSetDevice(h->cfg.device));
+  h->args.seed_lo = (uint32_t)seed;
+  h->args.seed_hi = (uint32_t)(seed >> 32);
+  h->args.major = episode;
+  MT_DISPATCH_D(h->D, launch_reset_d, h, mode);
+  int rc = check_launch(h, "reset_kernel");
+  if (rc) return rc;
+  h->is_reset = true;
+  return MT_OK;
+}
+
+int mt_reset_random(mt_handle h, uint64_t seed, uint32_t episode) { return reset_random_impl(h, seed, episode, 1); }
+
+int mt_reset_done(mt_handle h, uint64_t seed, uint32_t episode) {
+  MT_REQUIRE(nullptr, h != nullptr, "handle is NULL");
+  if (!h->is_reset) return fail(h, MT_ERR_STATE, "mt_reset_done before the first reset");
+  return reset_random_impl(h, seed, episode, 2);
+}
+
+// ---- actions ----------------------------------------------------------------------------------
+int mt_set_actions(mt_handle h, const void* actions, int dtype, int layout, int is_device) {
+  MT_REQUIRE(nullptr, h != nullptr, "handle is NULL");
+  MT_REQUIRE(h, actions != nullptr, "actions is NULL");
+  MT_REQUIRE(h, layout == MT_ENV_MAJOR || layout == MT_SOA, "bad layout");
+  MT_REQUIRE(h, dtype == MT_F32 || dtype == MT_F64 || dtype == MT_I32 || dtype == MT_I64, "bad action dtype");
+  MT_HIP(h, hipSetDevice(h->cfg.device));
+  const size_t es = (dtype == MT_F32 || dtype == MT_I32) ? 4 : 8;
+  const int64_t cols = (layout == MT_SOA) ? h->ld : h->n;
+  const size_t bytes = (size_t)h->D * cols * es;
+  const void* src = actions;
+  if (layout == MT_SOA && dtype == MT_F32) {
+    MT_HIP(h, hipMemcpyAsync(h->args.actions, actions, bytes,
+                             is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, h->stream));
+    if (!is_device) MT_HIP(h, hipStreamSynchronize(h->stream));
+    return MT_OK;
+  }
+  if (!is_device) {
+    int rc = ensure_staging(h, bytes);
+    if (rc) return rc;
+    MT_HIP(h, hipMemcpyAsync(h->staging, actions, bytes, hipMemcpyHostToDevice, h->stream));
+    src = h->staging;
+  }
+  const dim3 g = grid_for(h->n), b(kBlock);
+  if (layout == MT_ENV_MAJOR) {
+    switch (dtype) {
+      case MT_F32: hipLaunchKernelGGL((env_major_to_soa<float>), g, b, 0, h->stream, (const float*)src, h->D, h->n, h->args.actions, h->ld); break;
+      case MT_F64: hipLaunchKernelGGL((env_major_to_soa<double>), g, b, 0, h->stream, (const double*)src, h->D, h->n, h->args.actions, h->ld); break;
+      case MT_I32: hipLaunchKernelGGL((env_major_to_soa<int32_t>), g, b, 0, h->stream, (const int32_t*)src, h->D, h->n, h->args.actions, h->ld); break;
+      default: hipLaunchKernelGGL((env_major_to_soa<int64_t>), g, b, 0, h->stream, (const int64_t*)src, h->D, h->n, h->args.actions, h->ld); break;
+    }
+  } else {
+    switch (dtype) {
+      case MT_F64: hipLaunchKernelGGL((soa_to_soa_f32<double>), g, b, 0, h->stream, (const double*)src, h->D, h->n, h->ld, h->args.actions); break;
+      case MT_I32: hipLaunchKernelGGL((soa_to_soa_f32<int32_t>), g, b, 0, h->stream, (const int32_t*)src, h->D, h->n, h->ld, h->args.actions); break;
+      default: hipLaunchKernelGGL((soa_to_soa_f32<int64_t>), g, b, 0, h->stream, (const int64_t*)src, h->D, h->n, h->ld, h->args.actions); break;
+    }
+  }
+  int rc = check_launch(h, "set_actions");
+  if (rc) return rc;
+  if (!is_device) MT_HIP(h, hipStreamSynchronize(h->stream));
+  return MT_OK;
+}
+
+int mt_sample_actions(mt_handle h, uint64_t seed, uint32_t step_idx) {
+  MT_REQUIRE(nullptr, h != nullptr, "handle is NULL");
+  MT_HIP(h, hipSetDevice(h->cfg.device));
+  hipLaunchKernelGGL(sample_actions_kernel, grid_for(h->n), dim3(kBlock), 0, h->stream, h->args.actions, h->n, h->ld,
+                     h->D, h->args.env_base, seed, step_idx);
+  return check_launch(h, "sample_actions_kernel");
+}
+
+// ---- step -------------------------------------------------------------------------------------
+int mt_step(mt_handle h) {
+  MT_REQUIRE(nullptr, h != nullptr, "handle is NULL");
+  if (!h->is_reset) return fail(h, MT_ERR_STATE, "mt_step before mt_reset / mt_reset_random");
+  MT_HIP(h, hipSetDevice(h->cfg.device));
+  MT_DISPATCH_D(h->D, launch_step_d, h, false);
+  return check_launch(h, "step_kernel");
+}
+
+int mt_step_random(mt_handle h, uint64_t seed, uint32_t step_idx) {
+  MT_REQUIRE(nullptr, h != nullptr, "handle is NULL");
+  if (!h->is_reset) return fail(h, MT_ERR_STATE, "mt_step_random before mt_reset / mt_reset_random");
+  MT_HIP(h, hipSetDevice(h->cfg.device));
+  h->args.seed_lo = (uint32_t)seed;
+  h->args.seed_hi = (uint32_t)(seed >> 32);
+  h->args.major = step_idx;
+  MT_DISPATCH_D(h->D, launch_step_d, h, true);
+  return check_launch(h, "step_kernel");
+}
+
+int mt_rollout(mt_handle h, int n_steps, uint64_t seed, uint32_t step_idx0) {
+  MT_REQUIRE(nullptr, h != nullptr, "handle is NULL");
+  MT_REQUIRE(h, n_steps >= 0, "n_steps must be >= 0");
+  for (int s = 0; s < n_steps; ++s) {
+    int rc = mt_step_random(h, seed, step_idx0 + (uint32_t)s);
+    if (rc) return rc;
+  }
+  return MT_OK;
+}
+
+int mt_observe(mt_handle h) {
+  MT_REQUIRE(nullptr, h != nullptr, "handle is NULL");
+  if (!h->is_reset) return fail(h, MT_ERR_STATE, "mt_observe before reset");
+  MT_HIP(h, hipSetDevice(h->cfg.device));
+  MT_DISPATCH_D(h->D, launch_observe_d, h);
+  return check_launch(h, "observe_kernel");
+}
+
+int mt_check_done(mt_handle h) {
+  MT_REQUIRE(nullptr, h != nullptr, "handle is NULL");
+  if (!h->is_reset) return fail(h, MT_ERR_STATE, "mt_check_done before reset");
+  MT_HIP(h, hipSetDevice(h->cfg.device));
+  MT_DISPATCH_D(h->D, launch_check_done_d, h);
+  return check_launch(h, "check_done_kernel");
+}
+
+// ---- getters / setters ------------------------------------------------------------------------
+static int64_t env_major_bytes(mt_handle h, int field) {
+  const int64_t n = h->n;
+  switch (field) {
+    case MT_F_ACTIONS:
+    case MT_F_GOALS: return n * h->D * 4;
+    case MT_F_POINTS:
+    case MT_F_OBS: return n * 3 * h->K * 4;
+    case MT_F_ALIVE: return n * h->K;
+    case MT_F_REWARD:
+    case MT_F_TOTAL_REWARD: return n * 4;
+    case MT_F_DONE: return n;
+    case MT_F_DONE_BITS: return (n + 63) / 64 * 8;
+    case MT_F_EE: return n * 3 * 4;
+    case MT_F_JOINTS: return n * h->D * 3 * 4;
+    default: return -1;
+  }
+}
+
+int mt_get(mt_handle h, int field, void* dst, int64_t dst_bytes, int is_device) {
+  MT_REQUIRE(nullptr, h != nullptr, "handle is NULL");
+  MT_REQUIRE(h, dst != nullptr, "dst is NULL");
+  const int64_t need = env_major_bytes(h, field);
+  MT_REQUIRE(h, need > 0, "unknown field");
+  MT_REQUIRE(h, dst_bytes == need, "dst_bytes does not match the field's env-major size");
+  MT_HIP(h, hipSetDevice(h->cfg.device));
+  const dim3 g = grid_for(h->n), b(kBlock);
+  void* out = dst;
+  if (!is_device) {
+    int rc = ensure_staging(h, (size_t)need);
+    if (rc) return rc;
+    out = h->staging;
+  }
+  const StepArgs& a = h->args;
+  bool direct = false;  // single-row fields need no transpose
+  const void* direct_src = nullptr;
+  switch (field) {
+    case MT_F_ACTIONS: hipLaunchKernelGGL((soa_to_env_major<float>), g, b, 0, h->stream, a.actions, h->ld, h->D, h->n, (float*)out); break;
+    case MT_F_GOALS: hipLaunchKernelGGL((soa_to_env_major<float>), g, b, 0, h->stream, a.goals, h->ld, h->D, h->n, (float*)out); break;
+    case MT_F_POINTS: hipLaunchKernelGGL((soa_to_env_major<float>), g, b, 0, h->stream, a.points, h->ld, 3 * h->K, h->n, (float*)out); break;
+    case MT_F_OBS: hipLaunchKernelGGL((soa_to_env_major<float>), g, b, 0, h->stream, a.obs, h->ld, 3 * h->K, h->n, (float*)out); break;
+    case MT_F_EE: hipLaunchKernelGGL((soa_to_env_major<float>), g, b, 0, h->stream, a.ee, h->ld, 3, h->n, (float*)out); break;
+    case MT_F_ALIVE: hipLaunchKernelGGL(alive_unpack, g, b, 0, h->stream, a.alive, h->K, h->n, (uint8_t*)out); break;
+    case MT_F_JOINTS: MT_DISPATCH_D(h->D, launch_joints_d, h, (float*)out); break;
+    case MT_F_REWARD: direct = true; direct_src = a.reward; break;
+    case MT_F_TOTAL_REWARD: direct = true; direct_src = a.total_reward; break;
+    case MT_F_DONE: direct = true; direct_src = a.done; break;
+    case MT_F_DONE_BITS: direct = true; direct_src = a.done_bits; break;
+    default: return fail(h, MT_ERR_INVALID_ARG, "unknown field");
+  }
+  if (direct) {
+    MT_HIP(h, hipMemcpyAsync(dst, direct_src, (size_t)need, is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost,
+                             h->stream));
+  } else {
+    int rc = check_launch(h, "mt_get transpose");
+    if (rc) return rc;
+    if (!is_device) MT_HIP(h, hipMemcpyAsync(dst, h->staging, (size_t)need, hipMemcpyDeviceToHost, h->stream));
+  }
+  if (!is_device) MT_HIP(h, hipStreamSynchronize(h->stream));
+  return MT_OK;
+}
+
+int mt_set(mt_handle h, int field, const void* src, int64_t src_bytes) {
+  MT_REQUIRE(nullptr, h != nullptr, "handle is NULL");
+  MT_REQUIRE(h, src != nullptr, "src is NULL");
+  MT_REQUIRE(h, field == MT_F_GOALS || field == MT_F_POINTS || field == MT_F_ALIVE || field == MT_F_TOTAL_REWARD,
+             "field is not settable");
+  const int64_t need = env_major_bytes(h, field);
+  MT_REQUIRE(h, src_bytes == need, "src_bytes does not match the field's env-major size");
+  MT_HIP(h, hipSetDevice(h->cfg.device));
+  const dim3 g = grid_for(h->n), b(kBlock);
+  const StepArgs& a = h->args;
+  if (field == MT_F_TOTAL_REWARD) {
+    MT_HIP(h, hipMemcpyAsync(a.total_reward, src, (size_t)need, hipMemcpyHostToDevice, h->stream));
+  } else {
+    int rc = ensure_staging(h, (size_t)need);
+    if (rc) return rc;
+    MT_HIP(h, hipMemcpyAsync(h->staging, src, (size_t)need, hipMemcpyHostToDevice, h->stream));
+    if (field == MT_F_GOALS)
+      hipLaunchKernelGGL((env_major_to_soa<float>), g, b, 0, h->stream, (const float*)h->staging, h->D, h->n, a.goals, h->ld);
+    else if (field == MT_F_POINTS)
+      hipLaunchKernelGGL((env_major_to_soa<float>), g, b, 0, h->stream, (const float*)h->staging, 3 * h->K, h->n, a.points, h->ld);
+    else
+      hipLaunchKernelGGL(alive_pack, g, b, 0, h->stream, (const uint8_t*)h->staging, h->K, h->n, a.alive);
+    rc = check_launch(h, "mt_set");
+    if (rc) return rc;
+  }
+  MT_HIP(h, hipStreamSynchronize(h->stream));
+  return MT_OK;
+}
+
+int mt_device_ptr(mt_handle h, int field, void** ptr, int64_t* rows, int64_t* ld, int* dtype) {
+  MT_REQUIRE(nullptr, h != nullptr, "handle is NULL");
+  MT_REQUIRE(h, ptr != nullptr, "ptr is NULL");
+  FieldInfo fi{};
+  int rc = field_info(h, field, &fi);
+  if (rc) return rc;
+  *ptr = fi.ptr;
+  if (rows) *rows = fi.rows;
+  if (ld) *ld = (field == MT_F_DONE_BITS) ? h->ld / 64 : h->ld;
+  if (dtype) *dtype = fi.dtype;
+  return MT_OK;
+}
+
+// ---- timing -----------------------------------------------------------------------------------
+int mt_timer_start(mt_handle h) {
+  MT_REQUIRE(nullptr, h != nullptr, "handle is NULL");
+  MT_HIP(h, hipEventRecord(h->ev0, h->stream));
+  return MT_OK;
+}
+
+int mt_timer_stop(mt_handle h, float* elapsed_ms) {
+  MT_REQUIRE(nullptr, h != nullptr, "handle is NULL");
+  MT_REQUIRE(h, elapsed_ms != nullptr, "elapsed_ms is NULL");
+  MT_HIP(h, hipEventRecord(h->ev1, h->stream));
+  MT_HIP(h, hipEventSynchronize(h->ev1));
+  MT_HIP(h, hipEventElapsedTime(elapsed_ms, h->ev0, h->ev1));
+  return MT_OK;
+}
+
+// ---- stateless helpers ------------------------------------------------------------------------
+int mt_fk_batch(int device, const float* dh_table, int dof, int mode, const float* angles, int angles_in_radians,
+                int64_t n, float* out_mat16) {
+  MT_REQUIRE(nullptr, dh_table && angles && out_mat16, "NULL argument");
+  MT_REQUIRE(nullptr, dof >= 1 && dof <= MT_MAX_DOF && mode >= 0 && mode <= dof, "dof/mode out of range");
+  MT_REQUIRE(nullptr, n >= 1, "n must be >= 1");
+  MT_HIP(nullptr, hipSetDevice(device));
+  float *d_in = nullptr, *d_out = nullptr;
+  MT_HIP(nullptr, hipMalloc(&d_in, (size_t)n * dof * 4));
+  if (hipMalloc(&d_out, (size_t)n * 64) != hipSuccess) {
+    (void)hipFree(d_in);
+    return fail(nullptr, MT_ERR_ALLOC, "hipMalloc failed");
+  }
+  int rc = MT_OK;
+  FkArgs a{d_in, d_out, n, dof, mode, angles_in_radians, make_dh(dh_table, dof)};
+  hipError_t e = hipMemcpy(d_in, angles, (size_t)n * dof * 4, hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(fk_kernel, grid_for(n), dim3(kBlock), 0, 0, a);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpy(out_mat16, d_out, (size_t)n * 64, hipMemcpyDeviceToHost);
+  if (e != hipSuccess) rc = fail(nullptr, MT_ERR_HIP, std::string("mt_fk_batch: ") + hipGetErrorString(e));
+  (void)hipFree(d_in);
+  (void)hipFree(d_out);
+  return rc;
+}
+
+int mt_r_theta_batch(int device, const float* v1, const float* v2, int64_t n, float* out_r_theta) {
+  MT_REQUIRE(nullptr, v1 && v2 && out_r_theta, "NULL argument");
+  MT_REQUIRE(nullptr, n >= 1, "n must be >= 1");
+  MT_HIP(nullptr, hipSetDevice(device));
+  float* d = nullptr;
+  MT_HIP(nullptr, hipMalloc(&d, (size_t)n * 8 * 4));
+  float *d1 = d, *d2 = d + 3 * n, *dout = d + 6 * n;
+  int rc = MT_OK;
+  hipError_t e = hipMemcpy(d1, v1, (size_t)n * 12, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d2, v2, (size_t)n * 12, hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(r_theta_kernel, grid_for(n), dim3(kBlock), 0, 0, d1, d2, n, dout);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpy(out_r_theta, dout, (size_t)n * 8, hipMemcpyDeviceToHost);
+  if (e != hipSuccess) rc = fail(nullptr, MT_ERR_HIP, std::string("mt_r_theta_batch: ") + hipGetErrorString(e));
+  (void)hipFree(d);
+  return rc;
+}
+
+}  // extern "C"

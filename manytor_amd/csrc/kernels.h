@@ -1,0 +1,499 @@
+// HIP kernels of the ManyTor step engine (gfx950, wave64).
+//
+// One thread = one environment.  State is struct-of-arrays with row stride
+// `ld`, so every load/store below is a fully coalesced row access
+// (lane l of a wave touches element 64*w + l of a row).
+//
+// Reference semantics restated here (file:line = /root/reference/manytor.py):
+//   dh()               :25-32   one DH row = Rz(theta) Tz(d) Tx(a) Rx(alpha)
+//   fk()               :35-53   product of the first `mode` rows, degrees in
+//   get_observations() :141-153 from joints_coordinates[-2] (the elbow)
+//   is_done()          :155-173 from joints_coordinates[-1] (the end effector)
+//   action()           :175-213 25 interpolated sub-steps, ground flag, reward
+//   step()             :255-260
+//   reset()            :219-253
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/manytor_hip.h"
+#include "mt_math.h"
+#include "philox.h"
+
+namespace mt {
+
+constexpr int kBlock = 256;  // 4 wavefronts
+
+// Per-joint DH constants, uniform over the launch.  Passed by value in the
+// kernel arguments, so they live in SGPRs (s_load from the kernarg segment);
+// the MT_FLAG_DH_IN_LDS variant copies them to LDS first.
+struct DhConst {
+  float a[MT_MAX_DOF];
+  float d[MT_MAX_DOF];
+  float sa[MT_MAX_DOF];       // sin(alpha)
+  float ca[MT_MAX_DOF];       // cos(alpha)
+  float off_deg[MT_MAX_DOF];  // theta offset, degrees
+};
+
+struct StepArgs {
+  float* actions;                 // [D][ld]
+  float* goals;                   // [D][ld]
+  float* points;                  // [3K][ld]
+  uint32_t* alive;                // [ld] bit p = target p alive
+  float* total_reward;            // [ld]
+  float* obs;                     // [3K][ld]
+  int32_t* reward;                // [ld]
+  uint8_t* done;                  // [ld]
+  unsigned long long* done_bits;  // [ld/64]
+  float* ee;                      // [3][ld]
+  int64_t n, ld, env_base;
+  int32_t K, S;
+  float tol, inv_sm1;
+  uint32_t flags;
+  uint32_t seed_lo, seed_hi, major;  // RNG key + step / episode index
+  DhConst dh;
+};
+
+// ---------------------------------------------------------------------------
+// DH chain.  R = [X Y Z] (columns), p = origin.  One joint:
+//   X' = X c + Y s ;  T = Y c - X s ;  Y' = T ca + Z sa ;  Z' = Z ca - T sa
+//   p' = p + a X' + d Z
+// which is R' = R * M(theta, alpha), p' = p + R * (a c, a s, d) for the matrix
+// M of manytor.py:28-31.
+// ---------------------------------------------------------------------------
+template <int D>
+__device__ __forceinline__ void chain_all(const float (&s)[D], const float (&c)[D], const DhConst& t,
+                                          float (&p)[D][3]) {
+  float X[3] = {1.f, 0.f, 0.f}, Y[3] = {0.f, 1.f, 0.f}, Z[3] = {0.f, 0.f, 1.f};
+  float o[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < D; ++j) {
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const float nx = X[q] * c[j] + Y[q] * s[j];
+      const float tt = Y[q] * c[j] - X[q] * s[j];
+      o[q] += t.a[j] * nx + t.d[j] * Z[q];
+      X[q] = nx;
+      Y[q] = tt * t.ca[j] + Z[q] * t.sa[j];
+      Z[q] = Z[q] * t.ca[j] - tt * t.sa[j];
+      p[j][q] = o[q];
+    }
+  }
+}
+
+// z components only, of the frames after D-1 and after D joints: what the
+// ground test of manytor.py:191 needs.  Joint 0's angle drops out (the z row of
+// the identity is (0,0,1)), which the compiler sees after unrolling.
+template <int D>
+__device__ __forceinline__ void chain_z(const float (&s)[D], const float (&c)[D], const DhConst& t, float& z_obs,
+                                        float& z_ee) {
+  float x = 0.f, y = 0.f, z = 1.f, o = 0.f;
+  z_obs = 0.f;
+#pragma unroll
+  for (int j = 0; j < D; ++j) {
+    const float nx = x * c[j] + y * s[j];
+    const float tt = y * c[j] - x * s[j];
+    o += t.a[j] * nx + t.d[j] * z;
+    x = nx;
+    y = tt * t.ca[j] + z * t.sa[j];
+    z = z * t.ca[j] - tt * t.sa[j];
+    if (j == D - 2 && D > 2) z_obs = o;
+  }
+  z_ee = o;
+}
+
+// One target: observation triple (manytor.py:150-152, :17-22) and pickup test
+// (manytor.py:160-168).
+__device__ __forceinline__ void observe_target(const float (&el)[3], float x, float y, float z, float& dist, float& r,
+                                               float& th) {
+  const float m0 = fabsf(el[0] - x), m1 = fabsf(el[1] - y), m2 = fabsf(el[2] - z);
+  const float h2 = m0 * m0 + m1 * m1;
+  const float h = __builtin_sqrtf(h2);
+  dist = __builtin_sqrtf(h2 + m2 * m2);
+  r = atan2_deg_q1(m0, m1);
+  th = atan2_deg_q1(h, m2);
+}
+
+__device__ __forceinline__ bool within_box(const float (&e)[3], float x, float y, float z, float tol) {
+  return (fabsf(e[0] - x) <= tol) && (fabsf(e[1] - y) <= tol) && (fabsf(e[2] - z) <= tol);
+}
+
+// ---------------------------------------------------------------------------
+// step: Environment.step() for all envs (manytor.py:255-260 + :175-213).
+//   SAMPLE : draw the action in-kernel (== sample_actions_kernel then step)
+//   VARIANT: 0 polynomial trig, DH constants in SGPRs
+//            1 hardware v_sin/v_cos for the S-1 intermediate sub-steps
+//            2 DH constants staged in LDS
+// ---------------------------------------------------------------------------
+template <int D, bool SAMPLE, int VARIANT>
+__global__ __launch_bounds__(kBlock) void step_kernel(const StepArgs a) {
+  __shared__ DhConst sh;
+  if (VARIANT == 2) {
+    const float* src = reinterpret_cast<const float*>(&a.dh);
+    float* dst = reinterpret_cast<float*>(&sh);
+    if (threadIdx.x < sizeof(DhConst) / sizeof(float)) dst[threadIdx.x] = src[threadIdx.x];
+    __syncthreads();
+  }
+  const DhConst& t = (VARIANT == 2) ? sh : a.dh;
+
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= a.n) return;
+  const int64_t ld = a.ld;
+
+  float g[D], act[D];
+#pragma unroll
+  for (int j = 0; j < D; ++j) g[j] = a.goals[j * ld + i];
+  if (SAMPLE) {
+#pragma unroll
+    for (int b = 0; b < (D + 3) / 4; ++b) {
+      const u32x4 w = stream_block(((uint64_t)a.seed_hi << 32) | a.seed_lo, (uint64_t)(a.env_base + i), kTagAction,
+                                   a.major, (uint32_t)b);
+      const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (4 * b + q < D) act[4 * b + q] = action_from_word(ws[q]);
+    }
+#pragma unroll
+    for (int j = 0; j < D; ++j) a.actions[j * ld + i] = act[j];
+  } else {
+#pragma unroll
+    for (int j = 0; j < D; ++j) act[j] = a.actions[j * ld + i];
+  }
+
+  // route[k] = goals + k * (action - goals) / (S-1), route[S-1] = action (np.linspace, manytor.py:182)
+  float gq[D], st[D];
+#pragma unroll
+  for (int j = 0; j < D; ++j) {
+    st[j] = (act[j] - g[j]) * a.inv_sm1;
+    gq[j] = g[j] + t.off_deg[j];
+  }
+
+  bool ground = false;
+  float s[D], c[D];
+  s[0] = 0.f;
+  c[0] = 1.f;
+  for (int k = 0; k < a.S - 1; ++k) {  // sub-steps 0..S-2: only the ground flag is consumed (manytor.py:191)
+    const float fk = (float)k;
+#pragma unroll
+    for (int j = 1; j < D; ++j) {
+      const float pose = __builtin_fmaf(fk, st[j], gq[j]);
+      if (VARIANT == 1)
+        sincos_deg_hw(pose, s[j], c[j]);
+      else
+        sincos_deg(pose, s[j], c[j]);
+    }
+    float zo, ze;
+    chain_z<D>(s, c, t, zo, ze);
+    ground |= (zo < 0.f) | (ze < 0.f);
+  }
+
+  // final pose = the action itself
+  float p[D][3];
+#pragma unroll
+  for (int j = 0; j < D; ++j) sincos_deg(act[j] + t.off_deg[j], s[j], c[j]);
+  chain_all<D>(s, c, t, p);
+  float el[3], e[3];
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    el[q] = (D > 2) ? p[D - 2][q] : 0.f;  // joints_coordinates[-2]; row 0 is zeros (manytor.py:189)
+    e[q] = p[D - 1][q];
+  }
+  ground |= (el[2] < 0.f) | (e[2] < 0.f);
+
+  // obs2 (before pickup, manytor.py:204) and pickup (manytor.py:206) per target
+  const uint32_t am = a.alive[i];
+  uint32_t nam = am;
+  for (int k = 0; k < a.K; ++k) {
+    float* px = a.points + (int64_t)(3 * k) * ld + i;
+    float x = px[0], y = px[ld], z = px[2 * ld];
+    const bool al = (am >> k) & 1u;
+    float dist = 0.f, r = 0.f, th = 0.f;
+    if (al) {
+      observe_target(el, x, y, z, dist, r, th);
+      if (within_box(e, x, y, z, a.tol)) nam &= ~(1u << k);
+    } else if ((x != 0.f) | (y != 0.f) | (z != 0.f)) {  // manytor.py:148, first observation after death
+      px[0] = 0.f;
+      px[ld] = 0.f;
+      px[2 * ld] = 0.f;
+    }
+    float* po = a.obs + (int64_t)(3 * k) * ld + i;
+    po[0] = dist;
+    po[ld] = r;
+    po[2 * ld] = th;
+  }
+
+  const int32_t rew = ground ? -1 : ((nam != am) ? 1 : 0);  // manytor.py:205-212
+  bool done = (nam == 0u);                                    // manytor.py:170-171
+  if (a.flags & MT_FLAG_TERMINATE_ON_GROUND) done |= ground;
+
+#pragma unroll
+  for (int j = 0; j < D; ++j) a.goals[j * ld + i] = act[j];
+#pragma unroll
+  for (int q = 0; q < 3; ++q) a.ee[q * ld + i] = e[q];
+  a.alive[i] = nam;
+  a.reward[i] = rew;
+  a.total_reward[i] += (float)rew;  // manytor.py:258
+  a.done[i] = done ? 1 : 0;
+  const unsigned long long bits = __ballot(done);
+  if ((threadIdx.x & 63) == 0) a.done_bits[i >> 6] = bits;
+}
+
+// One rejection-sampling candidate of manytor.py:229-239 from one Philox block.
+// Contraction is off so that every op rounds once, exactly as the numpy
+// restatement (oracle/philox_ref.py) does.
+__device__ __forceinline__ bool target_candidate(const u32x4& w, float radius, float& x, float& y, float& z) {
+#pragma clang fp contract(off)
+  const float r2 = 2.0f * radius;
+  const float rr = radius * radius;
+  const float tx = r2 * u01(w.x);
+  const float ty = r2 * u01(w.y);
+  x = tx - radius;
+  y = ty - radius;
+  z = radius * u01(w.z);
+  const float xx = x * x, yy = y * y, zz = z * z;
+  const float sxy = xx + yy;
+  const float n2 = sxy + zz;
+  return n2 <= rr;
+}
+
+// ---------------------------------------------------------------------------
+// action_sample for all envs (manytor.py:215-217), device RNG.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void sample_actions_kernel(float* actions, int64_t n, int64_t ld, int D,
+                                                                int64_t env_base, uint64_t seed, uint32_t step_idx) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  for (int b = 0; b < (D + 3) / 4; ++b) {
+    const u32x4 w = stream_block(seed, (uint64_t)(env_base + i), kTagAction, step_idx, (uint32_t)b);
+    const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
+    for (int q = 0; q < 4; ++q)
+      if (4 * b + q < D) actions[(int64_t)(4 * b + q) * ld + i] = action_from_word(ws[q]);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// reset (manytor.py:219-253).  RANDOM: draw the targets here; otherwise the
+// caller has already filled `points`.  ONLY_DONE: re-arm finished envs only.
+// ---------------------------------------------------------------------------
+template <int D, bool RANDOM, bool ONLY_DONE>
+__global__ __launch_bounds__(kBlock) void reset_kernel(const StepArgs a, float radius) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= a.n) return;
+  const int64_t ld = a.ld;
+  const bool go = ONLY_DONE ? (a.done[i] != 0) : true;
+  if (go) {
+    float s[D], c[D], p[D][3];
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      a.goals[j * ld + i] = 0.f;
+      sincos_deg(a.dh.off_deg[j], s[j], c[j]);
+    }
+    chain_all<D>(s, c, a.dh, p);  // joints_coordinates at the zero pose, manytor.py:224-225
+#pragma unroll
+    for (int q = 0; q < 3; ++q) a.ee[q * ld + i] = p[D - 1][q];
+    a.total_reward[i] = 0.f;
+    a.reward[i] = 0;
+    a.done[i] = 0;
+    a.alive[i] = (a.K >= 32) ? 0xFFFFFFFFu : ((1u << a.K) - 1u);
+    if (RANDOM) {
+      // manytor.py:229-239: uniform in the cube, keep z >= 0 and |p| <= radius.  z is drawn from
+      // [0, R) directly (same conditional law).  fp32, one rounding per op, mirrored by oracle/philox_ref.py.
+      const uint64_t seed = ((uint64_t)a.seed_hi << 32) | a.seed_lo;
+      int cnt = 0;
+      for (uint32_t draw = 0; draw < 4096u && cnt < a.K; ++draw) {
+        const u32x4 w = stream_block(seed, (uint64_t)(a.env_base + i), kTagTarget, a.major, draw);
+        float x, y, z;
+        if (target_candidate(w, radius, x, y, z)) {
+          float* px = a.points + (int64_t)(3 * cnt) * ld + i;
+          px[0] = x;
+          px[ld] = y;
+          px[2 * ld] = z;
+          ++cnt;
+        }
+      }
+      for (; cnt < a.K; ++cnt) {  // unreachable in practice (p < 1e-1000); keeps the loop bounded
+        float* px = a.points + (int64_t)(3 * cnt) * ld + i;
+        px[0] = 0.f;
+        px[ld] = 0.f;
+        px[2 * ld] = 0.5f * radius;
+      }
+    }
+  }
+  if ((threadIdx.x & 63) == 0) a.done_bits[i >> 6] = 0ull;  // every env of the wave has done == 0 now ...
+  if (ONLY_DONE) {
+    // ... unless it was not re-armed and is not done either: done stays 0; nothing to do.
+  }
+}
+
+// ---------------------------------------------------------------------------
+// get_observations() at the current pose (manytor.py:141-153).
+// ---------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(kBlock) void observe_kernel(const StepArgs a) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= a.n) return;
+  const int64_t ld = a.ld;
+  float s[D], c[D], p[D][3];
+#pragma unroll
+  for (int j = 0; j < D; ++j) sincos_deg(a.goals[j * ld + i] + a.dh.off_deg[j], s[j], c[j]);
+  chain_all<D>(s, c, a.dh, p);
+  float el[3];
+#pragma unroll
+  for (int q = 0; q < 3; ++q) el[q] = (D > 2) ? p[D - 2][q] : 0.f;
+  const uint32_t am = a.alive[i];
+  for (int k = 0; k < a.K; ++k) {
+    float* px = a.points + (int64_t)(3 * k) * ld + i;
+    const float x = px[0], y = px[ld], z = px[2 * ld];
+    float dist = 0.f, r = 0.f, th = 0.f;
+    if ((am >> k) & 1u) {
+      observe_target(el, x, y, z, dist, r, th);
+    } else if ((x != 0.f) | (y != 0.f) | (z != 0.f)) {
+      px[0] = 0.f;
+      px[ld] = 0.f;
+      px[2 * ld] = 0.f;
+    }
+    float* po = a.obs + (int64_t)(3 * k) * ld + i;
+    po[0] = dist;
+    po[ld] = r;
+    po[2 * ld] = th;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// is_done() at the current pose (manytor.py:155-173).
+// ---------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(kBlock) void check_done_kernel(const StepArgs a) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= a.n) return;
+  const int64_t ld = a.ld;
+  float s[D], c[D], p[D][3];
+#pragma unroll
+  for (int j = 0; j < D; ++j) sincos_deg(a.goals[j * ld + i] + a.dh.off_deg[j], s[j], c[j]);
+  chain_all<D>(s, c, a.dh, p);
+  float e[3];
+#pragma unroll
+  for (int q = 0; q < 3; ++q) e[q] = p[D - 1][q];
+  uint32_t am = a.alive[i];
+  for (int k = 0; k < a.K; ++k) {
+    if (!((am >> k) & 1u)) continue;
+    const float* px = a.points + (int64_t)(3 * k) * ld + i;
+    if (within_box(e, px[0], px[ld], px[2 * ld], a.tol)) am &= ~(1u << k);
+  }
+  a.alive[i] = am;
+  const bool done = (am == 0u);
+  a.done[i] = done ? 1 : 0;
+  const unsigned long long bits = __ballot(done);
+  if ((threadIdx.x & 63) == 0) a.done_bits[i >> 6] = bits;
+}
+
+// joints_coordinates for all envs, env-major (N, D, 3): row 0 zeros, row j the
+// frame after j+1 joints (manytor.py:188-189).
+template <int D>
+__global__ __launch_bounds__(kBlock) void joints_kernel(const StepArgs a, float* out) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= a.n) return;
+  float s[D], c[D], p[D][3];
+#pragma unroll
+  for (int j = 0; j < D; ++j) sincos_deg(a.goals[j * a.ld + i] + a.dh.off_deg[j], s[j], c[j]);
+  chain_all<D>(s, c, a.dh, p);
+  float* o = out + i * (int64_t)(3 * D);
+#pragma unroll
+  for (int j = 0; j < D; ++j)
+#pragma unroll
+    for (int q = 0; q < 3; ++q) o[3 * j + q] = (j == 0) ? 0.f : p[j][q];
+}
+
+// ---------------------------------------------------------------------------
+// Layout conversion between the resident SoA rows and the reference's
+// env-major arrays.  Off the hot path (host getters / setters only).
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(kBlock) void soa_to_env_major(const T* src, int64_t ld, int rows, int64_t n, T* dst) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  for (int r = 0; r < rows; ++r) dst[i * rows + r] = src[(int64_t)r * ld + i];
+}
+
+template <typename S>
+__global__ __launch_bounds__(kBlock) void env_major_to_soa(const S* src, int rows, int64_t n, float* dst, int64_t ld) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  for (int r = 0; r < rows; ++r) dst[(int64_t)r * ld + i] = (float)src[i * rows + r];
+}
+
+template <typename S>
+__global__ __launch_bounds__(kBlock) void soa_to_soa_f32(const S* src, int rows, int64_t n, int64_t ld, float* dst) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  for (int r = 0; r < rows; ++r) dst[(int64_t)r * ld + i] = (float)src[(int64_t)r * ld + i];
+}
+
+__global__ __launch_bounds__(kBlock) void alive_unpack(const uint32_t* mask, int K, int64_t n, uint8_t* dst) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t m = mask[i];
+  for (int k = 0; k < K; ++k) dst[i * K + k] = (m >> k) & 1u;
+}
+
+__global__ __launch_bounds__(kBlock) void alive_pack(const uint8_t* src, int K, int64_t n, uint32_t* mask) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  uint32_t m = 0;
+  for (int k = 0; k < K; ++k) m |= (src[i * K + k] ? 1u : 0u) << k;
+  mask[i] = m;
+}
+
+// ---------------------------------------------------------------------------
+// Stateless helpers: fk()/dh() (manytor.py:25-53) and r_theta() (:17-22).
+// ---------------------------------------------------------------------------
+struct FkArgs {
+  const float* angles;  // (n, dof)
+  float* out;           // (n, 16) row-major 4x4
+  int64_t n;
+  int dof, mode, radians;
+  DhConst dh;
+};
+
+__global__ __launch_bounds__(kBlock) void fk_kernel(const FkArgs a) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= a.n) return;
+  float X[3] = {1.f, 0.f, 0.f}, Y[3] = {0.f, 1.f, 0.f}, Z[3] = {0.f, 0.f, 1.f}, o[3] = {0.f, 0.f, 0.f};
+  for (int j = 0; j < a.mode; ++j) {
+    float ang = a.angles[i * a.dof + j];
+    if (a.radians) ang *= 57.29577951308232f;
+    float s, c;
+    sincos_deg(ang + a.dh.off_deg[j], s, c);
+    for (int q = 0; q < 3; ++q) {
+      const float nx = X[q] * c + Y[q] * s;
+      const float tt = Y[q] * c - X[q] * s;
+      o[q] += a.dh.a[j] * nx + a.dh.d[j] * Z[q];
+      X[q] = nx;
+      Y[q] = tt * a.dh.ca[j] + Z[q] * a.dh.sa[j];
+      Z[q] = Z[q] * a.dh.ca[j] - tt * a.dh.sa[j];
+    }
+  }
+  float* m = a.out + i * 16;
+  for (int q = 0; q < 3; ++q) {
+    m[4 * q + 0] = X[q];
+    m[4 * q + 1] = Y[q];
+    m[4 * q + 2] = Z[q];
+    m[4 * q + 3] = o[q];
+  }
+  m[12] = 0.f;
+  m[13] = 0.f;
+  m[14] = 0.f;
+  m[15] = 1.f;
+}
+
+__global__ __launch_bounds__(kBlock) void r_theta_kernel(const float* v1, const float* v2, int64_t n, float* out) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const float d0 = fabsf(v1[3 * i] - v2[3 * i]), d1 = fabsf(v1[3 * i + 1] - v2[3 * i + 1]),
+              d2 = fabsf(v1[3 * i + 2] - v2[3 * i + 2]);
+  const float h = __builtin_sqrtf(d0 * d0 + d1 * d1);
+  out[2 * i] = atan2_deg_q1(d0, d1);
+  out[2 * i + 1] = atan2_deg_q1(h, d2);
+}
+
+}  // namespace mt

@@ -1,0 +1,67 @@
+// Device math for the ManyTor step kernels (gfx950).  fp32 throughout.
+//
+// Trigonometry is done on DEGREES because that is the unit of the state
+// (manytor.py:39 converts per call): the quadrant reduction x - 90*rint(x/90)
+// is exact in fp32, so integer-degree poses (every action the reference's
+// action_sample produces, manytor.py:216) carry no argument-rounding error at
+// all.  Coefficients come from tools/gen_poly.py.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace mt {
+
+// sin and cos of x degrees, |x| <= 720 or so.  Max abs error ~8e-8.
+__device__ __forceinline__ void sincos_deg(float x, float& s, float& c) {
+  const float q = __builtin_rintf(x * (1.0f / 90.0f));
+  const float f = __builtin_fmaf(q, -90.0f, x);  // exact: |f| <= 45
+  const float z = f * f;
+  float ps = -9.621979952e-17f;
+  ps = __builtin_fmaf(ps, z, 1.349391605e-11f);
+  ps = __builtin_fmaf(ps, z, -8.860952789e-07f);
+  ps = __builtin_fmaf(ps, z, 1.745329238e-02f);
+  ps *= f;
+  float pc = 2.099184062e-19f;
+  pc = __builtin_fmaf(pc, z, -3.925190319e-14f);
+  pc = __builtin_fmaf(pc, z, 3.866319265e-09f);
+  pc = __builtin_fmaf(pc, z, -1.523087121e-04f);
+  pc = __builtin_fmaf(pc, z, 1.0f);
+  const int qi = (int)q;
+  // quadrant rotation: (s,c) -> q&1 ? (c,-s) : (s,c); q&2 ? negate both
+  const bool odd = qi & 1;
+  float ss = odd ? pc : ps;
+  float cc = odd ? -ps : pc;
+  const unsigned flip = (unsigned)(qi & 2) << 30;  // sign bit
+  s = __uint_as_float(__float_as_uint(ss) ^ flip);
+  c = __uint_as_float(__float_as_uint(cc) ^ flip);
+}
+
+// Hardware transcendental path: v_sin_f32 / v_cos_f32 take REVOLUTIONS.
+// Quarter-rate, ~1e-6 absolute; only used where a 1e-3 guard band applies
+// (the ground flag of intermediate sub-steps) and only under MT_FLAG_HW_TRIG.
+__device__ __forceinline__ void sincos_deg_hw(float x, float& s, float& c) {
+  const float rev = x * (1.0f / 360.0f);
+  s = __builtin_amdgcn_sinf(rev);
+  c = __builtin_amdgcn_cosf(rev);
+}
+
+// atan2(y, x) in DEGREES for y >= 0, x >= 0 (first quadrant only: the
+// reference takes |differences| first, manytor.py:18).  atan2(0,0) = 0 like
+// math.atan2.  Max abs error ~1e-5 degrees.
+__device__ __forceinline__ float atan2_deg_q1(float y, float x) {
+  const float mx = fmaxf(x, y);
+  const float mn = fminf(x, y);
+  const float q = (mx > 0.0f) ? mn * __builtin_amdgcn_rcpf(mx) : 0.0f;
+  const float w = q * q;
+  float p = -4.668773152e-03f;
+  p = __builtin_fmaf(p, w, 2.416618913e-02f);
+  p = __builtin_fmaf(p, w, -5.936710164e-02f);
+  p = __builtin_fmaf(p, w, 9.906096756e-02f);
+  p = __builtin_fmaf(p, w, -1.401658505e-01f);
+  p = __builtin_fmaf(p, w, 1.996923536e-01f);
+  p = __builtin_fmaf(p, w, -3.333196044e-01f);
+  p = __builtin_fmaf(p, w, 9.999998808e-01f);
+  const float a = p * q * 57.29577951308232f;  // degrees, in [0, 45]
+  return (y > x) ? 90.0f - a : a;
+}
+
+}  // namespace mt

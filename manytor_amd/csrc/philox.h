@@ -1,0 +1,52 @@
+// Counter-based RNG for the device-side reset / action_sample paths.
+//
+// The reference draws from numpy's global MT19937 in env order
+// (manytor.py:216, :231), which ties results to a serial loop.  Here every
+// draw is a pure function of (seed, GLOBAL env id, episode/step, draw index),
+// so any sharding of the envs over GPUs gives the same per-env stream.
+// Philox-4x32-10 as published (Salmon et al., SC'11); the numpy restatement in
+// oracle/philox_ref.py is pinned by the Random123 known-answer vectors and the
+// kernels are checked bit-for-bit against it.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mt {
+
+constexpr uint32_t kTagAction = 1u;
+constexpr uint32_t kTagTarget = 2u;
+
+struct u32x4 {
+  uint32_t x, y, z, w;
+};
+
+__host__ __device__ __forceinline__ uint32_t mulhi32(uint32_t a, uint32_t b) {
+  return (uint32_t)(((uint64_t)a * (uint64_t)b) >> 32);  // v_mul_hi_u32 on the device
+}
+
+__host__ __device__ __forceinline__ u32x4 philox4x32_10(u32x4 c, uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t hi0 = mulhi32(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
+    const uint32_t hi1 = mulhi32(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+    c = u32x4{hi1 ^ c.y ^ k0, lo1, hi0 ^ c.w ^ k1, lo0};
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  return c;
+}
+
+// counter = (env_lo, env_hi[23:0] | tag << 24, major, minor)
+__host__ __device__ __forceinline__ u32x4 stream_block(uint64_t seed, uint64_t env_id, uint32_t tag, uint32_t major,
+                                                       uint32_t minor) {
+  u32x4 c{(uint32_t)env_id, ((uint32_t)(env_id >> 32) & 0x00FFFFFFu) | (tag << 24), major, minor};
+  return philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+}
+
+// integer degrees uniform in [-180, 180)  (manytor.py:216)
+__host__ __device__ __forceinline__ float action_from_word(uint32_t w) { return (float)mulhi32(w, 360u) - 180.0f; }
+
+// u in [0,1) with 24 bits
+__host__ __device__ __forceinline__ float u01(uint32_t w) { return (float)(w >> 8) * 5.9604644775390625e-08f; }
+
+}  // namespace mt

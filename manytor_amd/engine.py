@@ -1,0 +1,340 @@
+"""StepEngine: thin object wrapper over one mt_handle (include/manytor_hip.h).
+
+One engine = N lock-stepped arms resident on one MI355X.  All arithmetic runs in
+the HIP kernels; this file only marshals arguments.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import _lib as L
+
+# DH rows (a, alpha, d, theta_offset) of the reference arm, manytor.py:42-48.
+REF_DH_TABLE = (
+    (0.0, -math.pi / 2, 4.3, 0.0),
+    (0.0, math.pi / 2, 0.0, 0.0),
+    (0.0, -math.pi / 2, 24.3, 0.0),
+    (27.0, math.pi / 2, 0.0, -math.pi / 2),
+)
+
+# A 7-joint table for the generalised-DH configuration (BASELINE.json configs[4]);
+# pinned by fixture F7 (tests/golden/f7_dh7_kat.npz).
+DH7_TABLE = (
+    (0.0, -math.pi / 2, 34.0, 0.0),
+    (0.0, math.pi / 2, 0.0, 0.0),
+    (4.5, math.pi / 2, 40.0, 0.0),
+    (-4.5, -math.pi / 2, 0.0, 0.0),
+    (0.0, -math.pi / 2, 40.0, 0.0),
+    (8.8, math.pi / 2, 0.0, -math.pi / 2),
+    (0.0, 0.0, 12.6, 0.0),
+)
+
+_NP_OF_DT = {L.DT_F32: np.float32, L.DT_I32: np.int32, L.DT_U8: np.uint8, L.DT_U32: np.uint32, L.DT_U64: np.uint64}
+_TYPESTR = {L.DT_F32: "<f4", L.DT_I32: "<i4", L.DT_U8: "|u1", L.DT_U32: "<u4", L.DT_U64: "<u8"}
+_ACTION_DT = {np.dtype(np.float32): L.DT_F32, np.dtype(np.float64): L.DT_F64, np.dtype(np.int32): L.DT_I32,
+              np.dtype(np.int64): L.DT_I64}
+
+
+def _is_torch_tensor(x) -> bool:
+    return type(x).__module__.startswith("torch") and hasattr(x, "data_ptr")
+
+
+class _CudaArrayHolder:
+    """Exposes a raw device range through __cuda_array_interface__ (consumed by torch.as_tensor)."""
+
+    def __init__(self, ptr, shape, strides, typestr, owner):
+        self.__cuda_array_interface__ = {
+            "shape": tuple(shape), "strides": tuple(strides), "typestr": typestr, "data": (int(ptr), False), "version": 2,
+        }
+        self._owner = owner     # keeps the engine (and its arena) alive
+
+
+class StepEngine:
+    """N lock-stepped manipulator envs on one GPU.
+
+    Mirrors, for a batch, the state and methods of the reference ``Environment``
+    (manytor.py:125-260): reset / step / get_observations / is_done /
+    action_sample.  Field getters return arrays in the reference's shapes with a
+    leading env axis.
+    """
+
+    def __init__(self, n_envs, obj_number=10, dh_table=REF_DH_TABLE, substeps=25, pickup_tol=8.0, radius=51.3,
+                 device=0, env_id_base=0, terminate_on_ground=False, hw_trig=False, dh_in_lds=False):
+        self._lib = L.load()
+        table = np.asarray(dh_table, dtype=np.float64)
+        if table.ndim != 2 or table.shape[1] != 4:
+            raise ValueError("dh_table must be (dof, 4): rows (a, alpha, d, theta_offset)")
+        self.n_envs = int(n_envs)
+        self.obj_number = int(obj_number)
+        self.dof = int(table.shape[0])
+        self.substeps = int(substeps)
+        self.device = int(device)
+        self.env_id_base = int(env_id_base)
+        self.dh_table = table
+        cfg = L.MtConfig()
+        cfg.struct_size = C.sizeof(L.MtConfig)
+        cfg.device = self.device
+        cfg.n_envs = self.n_envs
+        cfg.env_id_base = self.env_id_base
+        cfg.dof = self.dof
+        cfg.n_targets = self.obj_number
+        cfg.substeps = self.substeps
+        cfg.flags = ((L.FLAG_TERMINATE_ON_GROUND if terminate_on_ground else 0) | (L.FLAG_HW_TRIG if hw_trig else 0)
+                     | (L.FLAG_DH_IN_LDS if dh_in_lds else 0))
+        cfg.pickup_tol = float(pickup_tol)
+        cfg.radius = float(radius)
+        if self.dof > L.MT_MAX_DOF:
+            raise ValueError(f"dof must be <= {L.MT_MAX_DOF}")
+        flat = table.astype(np.float32).ravel()
+        for i, v in enumerate(flat):
+            cfg.dh_table[i] = float(v)
+        self._h = L._HANDLE()
+        L.check(self._lib.mt_create(C.byref(self._h), C.byref(cfg)))
+        self.version = 0          # bumped by every call that changes device state (host caches key on it)
+
+    # ---- lifetime ---------------------------------------------------------------------------
+    def close(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._lib.mt_destroy(h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _call(self, fn, *args):
+        if not self._h:
+            raise RuntimeError("StepEngine is closed")
+        L.check(fn(self._h, *args), self._h)
+
+    # ---- stream / sync / timing ---------------------------------------------------------------
+    def set_stream(self, hip_stream):
+        """Run on a caller-owned hipStream_t (int / pointer); None restores the engine's own stream."""
+        self._call(self._lib.mt_set_stream, C.c_void_p(int(hip_stream)) if hip_stream else None)
+
+    def use_torch_stream(self):
+        import torch
+        self.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def sync(self):
+        self._call(self._lib.mt_sync)
+
+    def timer_start(self):
+        self._call(self._lib.mt_timer_start)
+
+    def timer_stop(self) -> float:
+        ms = C.c_float(0)
+        self._call(self._lib.mt_timer_stop, C.byref(ms))
+        return ms.value
+
+    # ---- reset --------------------------------------------------------------------------------
+    def reset(self, points):
+        """Environment.reset (manytor.py:219-253) with caller-supplied targets: (N, K, 3) host array
+        or device tensor (env-major), or a (3K, ld) float32 device tensor (SoA)."""
+        n, k = self.n_envs, self.obj_number
+        if _is_torch_tensor(points):
+            import torch
+            t = points
+            if not t.is_cuda:
+                return self.reset(t.detach().cpu().numpy())
+            if t.dtype != torch.float32 or not t.is_contiguous():
+                t = t.to(torch.float32).contiguous()
+            if t.numel() == n * k * 3:
+                layout = L.ENV_MAJOR
+            elif tuple(t.shape) == (3 * k, self.ld):
+                layout = L.SOA
+            else:
+                raise ValueError("device points must be (N,K,3) or (3K, ld)")
+            torch.cuda.current_stream(self.device).synchronize()
+            self._call(self._lib.mt_reset, C.c_void_p(t.data_ptr()), layout, 1)
+            self.sync()
+        else:
+            p = np.ascontiguousarray(np.asarray(points, dtype=np.float32).reshape(n, k, 3))
+            self._call(self._lib.mt_reset, p.ctypes.data_as(C.c_void_p), L.ENV_MAJOR, 0)
+        self.version += 1
+
+    def reset_random(self, seed=0x5EED, episode=0):
+        self._call(self._lib.mt_reset_random, C.c_uint64(seed), C.c_uint32(episode))
+        self.version += 1
+
+    def reset_done(self, seed=0x5EED, episode=0):
+        self._call(self._lib.mt_reset_done, C.c_uint64(seed), C.c_uint32(episode))
+        self.version += 1
+
+    # ---- actions ------------------------------------------------------------------------------
+    def set_actions(self, actions):
+        """(N, D) degrees: nested lists, numpy (f32/f64/i32/i64) or a device tensor; or (D, ld) SoA device tensor."""
+        n, d = self.n_envs, self.dof
+        if _is_torch_tensor(actions) and actions.is_cuda:
+            import torch
+            t = actions
+            dt = {torch.float32: L.DT_F32, torch.float64: L.DT_F64, torch.int32: L.DT_I32, torch.int64: L.DT_I64}.get(t.dtype)
+            if dt is None:
+                t, dt = t.to(torch.float32), L.DT_F32
+            t = t.contiguous()
+            if tuple(t.shape) == (n, d):
+                layout = L.ENV_MAJOR
+            elif tuple(t.shape) == (d, self.ld):
+                layout = L.SOA
+            else:
+                raise ValueError(f"device actions must be ({n},{d}) or ({d},{self.ld})")
+            torch.cuda.current_stream(self.device).synchronize()
+            self._call(self._lib.mt_set_actions, C.c_void_p(t.data_ptr()), dt, layout, 1)
+            self.sync()
+            return
+        if _is_torch_tensor(actions):
+            actions = actions.detach().cpu().numpy()
+        a = np.asarray(actions)
+        if a.dtype not in _ACTION_DT:
+            a = a.astype(np.float64)
+        if a.size != n * d:
+            raise ValueError(f"actions must have {n}x{d} elements, got shape {a.shape}")
+        a = np.ascontiguousarray(a.reshape(n, d))
+        self._call(self._lib.mt_set_actions, a.ctypes.data_as(C.c_void_p), _ACTION_DT[a.dtype], L.ENV_MAJOR, 0)
+
+    def sample_actions(self, seed=0x5EED, step_idx=0):
+        """Environment.action_sample (manytor.py:215-217) on the device, into the action buffer."""
+        self._call(self._lib.mt_sample_actions, C.c_uint64(seed), C.c_uint32(step_idx))
+
+    # ---- step ---------------------------------------------------------------------------------
+    def step(self, actions=None):
+        """Environment.step (manytor.py:255-260) for all envs.  Results stay on the device:
+        read them with get()/device_tensor()."""
+        if actions is not None:
+            self.set_actions(actions)
+        self._call(self._lib.mt_step)
+        self.version += 1
+
+    def step_random(self, seed=0x5EED, step_idx=0):
+        self._call(self._lib.mt_step_random, C.c_uint64(seed), C.c_uint32(step_idx))
+        self.version += 1
+
+    def rollout(self, n_steps, seed=0x5EED, step_idx0=0):
+        self._call(self._lib.mt_rollout, int(n_steps), C.c_uint64(seed), C.c_uint32(step_idx0))
+        self.version += 1
+
+    def observe(self):
+        """Environment.get_observations (manytor.py:141-153); result in field OBS."""
+        self._call(self._lib.mt_observe)
+        self.version += 1
+
+    def check_done(self):
+        """Environment.is_done (manytor.py:155-173); result in field DONE."""
+        self._call(self._lib.mt_check_done)
+        self.version += 1
+
+    # ---- state access -------------------------------------------------------------------------
+    def _shape_dtype(self, field):
+        n, d, k = self.n_envs, self.dof, self.obj_number
+        return {
+            L.F_ACTIONS: ((n, d), np.float32), L.F_GOALS: ((n, d), np.float32), L.F_POINTS: ((n, k, 3), np.float32),
+            L.F_ALIVE: ((n, k), np.uint8), L.F_OBS: ((n, 3 * k), np.float32), L.F_REWARD: ((n,), np.int32),
+            L.F_DONE: ((n,), np.uint8), L.F_DONE_BITS: (((n + 63) // 64,), np.uint64), L.F_EE: ((n, 3), np.float32),
+            L.F_TOTAL_REWARD: ((n,), np.float32), L.F_JOINTS: ((n, d, 3), np.float32),
+        }[field]
+
+    def get(self, field) -> np.ndarray:
+        """Host copy of a field in the reference's shape (leading env axis)."""
+        shape, dt = self._shape_dtype(field)
+        out = np.empty(shape, dtype=dt)
+        self._call(self._lib.mt_get, field, out.ctypes.data_as(C.c_void_p), C.c_int64(out.nbytes), 0)
+        return out
+
+    def set(self, field, value):
+        shape, dt = self._shape_dtype(field)
+        v = np.ascontiguousarray(np.asarray(value).astype(dt).reshape(shape))
+        self._call(self._lib.mt_set, field, v.ctypes.data_as(C.c_void_p), C.c_int64(v.nbytes))
+        self.version += 1
+
+    def device_ptr(self, field):
+        ptr, rows, ld, dt = C.c_void_p(), C.c_int64(), C.c_int64(), C.c_int()
+        self._call(self._lib.mt_device_ptr, field, C.byref(ptr), C.byref(rows), C.byref(ld), C.byref(dt))
+        return ptr.value, rows.value, ld.value, dt.value
+
+    @property
+    def ld(self) -> int:
+        return self.device_ptr(L.F_GOALS)[2]
+
+    def device_tensor(self, field):
+        """Zero-copy torch view of the resident SoA buffer: shape (rows, N) (or (N,) for single-row fields,
+        (ceil(N/64),) for DONE_BITS).  `.T` gives the reference's (N, rows) orientation."""
+        import torch
+        ptr, rows, ld, dt = self.device_ptr(field)
+        es = np.dtype(_NP_OF_DT[dt]).itemsize
+        n = (self.n_envs + 63) // 64 if field == L.F_DONE_BITS else self.n_envs
+        if dt in (L.DT_U32, L.DT_U64):      # torch has limited unsigned support: expose as same-width signed
+            typestr = "<i4" if dt == L.DT_U32 else "<i8"
+        else:
+            typestr = _TYPESTR[dt]
+        shape, strides = ((n,), (es,)) if rows == 1 else ((rows, n), (ld * es, es))
+        holder = _CudaArrayHolder(ptr, shape, strides, typestr, self)
+        t = torch.as_tensor(holder, device=f"cuda:{self.device}")
+        t._manytor_owner = holder
+        return t
+
+    # convenience getters in the reference's vocabulary
+    def goals(self):
+        return self.get(L.F_GOALS)
+
+    def points(self):
+        return self.get(L.F_POINTS)
+
+    def alives(self):
+        return self.get(L.F_ALIVE).astype(bool)
+
+    def obs(self):
+        return self.get(L.F_OBS)
+
+    def reward(self):
+        return self.get(L.F_REWARD)
+
+    def done(self):
+        return self.get(L.F_DONE).astype(bool)
+
+    def done_bits(self):
+        return self.get(L.F_DONE_BITS)
+
+    def ee(self):
+        return self.get(L.F_EE)
+
+    def total_reward(self):
+        return self.get(L.F_TOTAL_REWARD)
+
+    def joints_coordinates(self):
+        return self.get(L.F_JOINTS)
+
+    def actions(self):
+        return self.get(L.F_ACTIONS)
+
+
+# ---- stateless helpers = module functions of the reference (manytor.py:17-53) -------------------
+def fk_batch(mode, angles, dh_table=REF_DH_TABLE, radians=False, device=0) -> np.ndarray:
+    lib = L.load()
+    table = np.ascontiguousarray(np.asarray(dh_table, dtype=np.float32))
+    dof = table.shape[0]
+    a = np.ascontiguousarray(np.asarray(angles, dtype=np.float32).reshape(-1, dof))
+    out = np.empty((a.shape[0], 4, 4), dtype=np.float32)
+    L.check(lib.mt_fk_batch(device, table.ctypes.data_as(C.c_void_p), dof, int(mode), a.ctypes.data_as(C.c_void_p),
+                            1 if radians else 0, C.c_int64(a.shape[0]), out.ctypes.data_as(C.c_void_p)))
+    return out
+
+
+def r_theta_batch(v1, v2, device=0) -> np.ndarray:
+    lib = L.load()
+    a = np.ascontiguousarray(np.asarray(v1, dtype=np.float32).reshape(-1, 3))
+    b = np.ascontiguousarray(np.asarray(v2, dtype=np.float32).reshape(-1, 3))
+    out = np.empty((a.shape[0], 2), dtype=np.float32)
+    L.check(lib.mt_r_theta_batch(device, a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p),
+                                 C.c_int64(a.shape[0]), out.ctypes.data_as(C.c_void_p)))
+    return out

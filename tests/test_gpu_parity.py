@@ -1,0 +1,569 @@
+"""GPU parity tests: the HIP path (through the C ABI / ctypes) against the golden fixtures produced by
+the reference and against the CPU oracle on seeded inputs.
+
+Tolerances (fp32 device arithmetic vs the reference's fp64):
+  positions            atol 1e-4
+  distance             atol 2e-4
+  angles (degrees)     atol max(1e-3, 57.3 * 1e-4 / rho)   rho = lever arm of the angle
+  reward/done/alives   exact, except where the oracle's own margin to the z = 0 or |delta| = tol threshold is
+                       below GUARD = 1e-3 (fp32 and fp64 may legitimately land on different sides); guarded
+                       cases are counted and must stay rare.
+Bit-exact: device RNG streams vs oracle/philox_ref.py, staged actions, goals, sharding invariance.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+POS_TOL = 1e-4
+DIST_TOL = 2e-4
+GUARD = 1e-3
+
+
+@pytest.fixture(scope="module")
+def m():
+    import manytor_amd
+    if manytor_amd.device_count() < 1:
+        pytest.fail("gpu tests need a visible MI355X and the in-tree libmanytor_hip.so")
+    return manytor_amd
+
+
+@pytest.fixture(scope="module")
+def mo():
+    from oracle import manytor_oracle
+    return manytor_oracle
+
+
+def assert_obs_close(obs, ref_obs, elbow, points, alive):
+    """obs, ref_obs (N,3K); elbow (N,3), points (N,K,3) and alive (N,K) from the oracle (pre-pickup state)."""
+    n, k = alive.shape
+    o = obs.reshape(n, k, 3).astype(np.float64)
+    r = ref_obs.reshape(n, k, 3)
+    m_ = np.abs(elbow[:, None, :] - points)
+    rho_xy = np.hypot(m_[..., 0], m_[..., 1])
+    dist = r[..., 0]
+    with np.errstate(divide="ignore"):
+        tol_r = np.maximum(1e-3, 57.3 * 1e-4 / rho_xy)
+        tol_th = np.maximum(1e-3, 57.3 * 1e-4 / dist)
+    dead = ~alive
+    assert np.all(o[dead] == 0.0)
+    assert np.all(np.abs(o[..., 0] - r[..., 0])[alive] <= DIST_TOL), np.abs(o[..., 0] - r[..., 0])[alive].max()
+    err_r = np.abs(o[..., 1] - r[..., 1])
+    err_t = np.abs(o[..., 2] - r[..., 2])
+    assert np.all((err_r <= tol_r)[alive]), (err_r - tol_r)[alive].max()
+    assert np.all((err_t <= tol_th)[alive]), (err_t - tol_th)[alive].max()
+
+
+class Lockstep:
+    """Drive a StepEngine and a BatchOracle with the same inputs; compare every output every step."""
+
+    def __init__(self, m, mo, n, k, table=None, substeps=25, **kw):
+        table = m.REF_DH_TABLE if table is None else table
+        self.eng = m.StepEngine(n, k, dh_table=table, substeps=substeps, **kw)
+        self.ora = mo.BatchOracle(n, k, table=np.asarray(table), substeps=substeps)
+        self.n, self.k = n, k
+        self.valid = np.ones(n, dtype=bool)      # envs whose discrete state is still comparable
+        self.guarded = 0
+        self.compared = 0
+
+    def reset(self, points):
+        p32 = np.asarray(points, dtype=np.float32).reshape(self.n, self.k, 3)
+        self.eng.reset(p32)
+        self.ora.reset(p32.astype(np.float64))
+        self.valid[:] = True
+        np.testing.assert_array_equal(self.eng.points(), p32)
+        assert np.all(self.eng.goals() == 0) and np.all(self.eng.total_reward() == 0) and self.eng.alives().all()
+        np.testing.assert_allclose(self.eng.joints_coordinates(), self.ora.joints_coordinates, atol=POS_TOL)
+        np.testing.assert_allclose(self.eng.ee(), self.ora.joints_coordinates[:, -1], atol=POS_TOL)
+
+    def step(self, actions):
+        e, o = self.eng, self.ora
+        pre_alive = o.alives.copy()
+        e.step(actions)
+        obs_ref, rew_ref, done_ref = o.step(actions)
+        pre_points = o.points.copy()              # after the zeroing of dead targets, before pickup bookkeeping
+        v = self.valid
+        # continuous outputs
+        np.testing.assert_array_equal(e.goals(), np.asarray(actions, dtype=np.float32).reshape(self.n, -1))
+        jc = e.joints_coordinates()
+        assert np.abs(jc - o.joints_coordinates).max() <= POS_TOL
+        assert np.abs(e.ee() - o.joints_coordinates[:, -1]).max() <= POS_TOL
+        if v.any():
+            assert_obs_close(e.obs()[v], obs_ref[v], o.joints_coordinates[v, -2], pre_points[v], pre_alive[v])
+        # discrete outputs under the guard band
+        pick_m = np.where(pre_alive, o.pickup_margin, np.inf).min(axis=1)
+        risky = (o.ground_margin < GUARD) | (pick_m < GUARD)
+        ok = v & ~risky
+        self.guarded += int((v & risky).sum())
+        self.compared += int(ok.sum())
+        np.testing.assert_array_equal(e.reward()[ok], rew_ref[ok])
+        np.testing.assert_array_equal(e.done()[ok], done_ref[ok])
+        np.testing.assert_array_equal(e.alives()[ok], o.alives[ok])
+        np.testing.assert_array_equal(e.total_reward()[ok], o.total_reward[ok].astype(np.float32))
+        # an env that was inside the guard band may have diverged legitimately: re-sync its discrete state
+        if (v & risky).any():
+            idx = np.flatnonzero(v & risky)
+            alive = e.alives()
+            o.alives[idx] = alive[idx]
+            o.total_reward[idx] = e.total_reward()[idx]
+            pts = e.points().astype(np.float64)
+            o.points[idx] = pts[idx]
+        # done bits are the wavefront ballot of the done bytes
+        done = e.done()
+        bits = e.done_bits()
+        unpacked = ((bits[:, None] >> np.arange(64, dtype=np.uint64)) & np.uint64(1)).astype(bool).ravel()[: self.n]
+        np.testing.assert_array_equal(unpacked, done)
+        return obs_ref, rew_ref, done_ref
+
+
+# --------------------------------------------------------------------------- L1 kinematics (F1, F7, F8)
+def test_f1_fk_positions_and_matrices(m, golden):
+    g = golden("f1_fk_kat")
+    for mode in range(1, 5):
+        mats = m.fk_batch(mode, g["angles"])
+        assert np.abs(mats - g["matrices"][:, mode - 1]).max() <= POS_TOL
+    out = m.fk(4, [30, 45, -60, 90])
+    assert out.shape == (4, 4) and out.dtype == np.float64
+    np.testing.assert_allclose(out[0:3, 3], [34.839021, -6.885682, 11.936753], atol=POS_TOL)
+    np.testing.assert_allclose(m.fk(4, [0, 0, 0, 0])[0:3, 3], [0, 0, 55.6], atol=1e-5)
+    for mode, z in ((1, 4.3), (2, 4.3), (3, 28.6), (4, 55.6)):
+        np.testing.assert_allclose(m.fk(mode, [0, 0, 0, 0])[0:3, 3], [0, 0, z], atol=1e-5)
+
+
+def test_f8_dh_and_r_theta(m, golden):
+    g = golden("f8_dh_rtheta_kat")
+    for p, ref in zip(g["dh_params"], g["dh_matrices"]):
+        assert np.abs(m.dh(*p) - ref).max() <= 2e-5
+    rt = m.r_theta_batch(g["v1"], g["v2"])
+    d = np.abs(g["v1"] - g["v2"])
+    rho = np.hypot(d[:, 0], d[:, 1])
+    full = np.sqrt(rho ** 2 + d[:, 2] ** 2)
+    with np.errstate(divide="ignore"):
+        assert np.all(np.abs(rt[:, 0] - g["r_theta"][:, 0]) <= np.maximum(1e-3, 57.3 * 1e-4 / rho))
+        assert np.all(np.abs(rt[:, 1] - g["r_theta"][:, 1]) <= np.maximum(1e-3, 57.3 * 1e-4 / full))
+    assert m.r_theta([1, 2, 3], [1, 2, 3]) == (0.0, 0.0)          # atan2(0, 0) = 0 like math.atan2
+
+
+def test_f7_seven_dof_chain(m, golden):
+    g = golden("f7_dh7_kat")
+    n = len(g["angles"])
+    eng = m.StepEngine(n, 3, dh_table=g["table"], radius=92.6)
+    eng.reset(np.zeros((n, 3, 3), dtype=np.float32))
+    eng.set(m.lib.F_GOALS, g["angles"].astype(np.float32))
+    jc = eng.joints_coordinates()
+    ref = g["positions"].copy()
+    ref[:, 0] = 0.0
+    a32 = g["angles"].astype(np.float32).astype(np.float64)       # compare at the fp32-rounded input angles
+    from oracle import manytor_oracle as mo
+    ref32 = mo.batch_joints_coordinates(a32, g["table"])
+    assert np.abs(jc - ref32).max() <= POS_TOL
+    assert np.abs(jc[: n // 2] - ref[: n // 2]).max() <= POS_TOL  # integer-degree half: no input rounding at all
+    mats = m.fk_batch(7, g["angles"], dh_table=g["table"])
+    assert np.abs(mats[: n // 2] - g["matrices"][: n // 2, 6]).max() <= POS_TOL
+
+
+# --------------------------------------------------------------------------- single env (F2), drop-in surface
+def test_f2_single_env_trace_through_environment_class(m, golden):
+    g = golden("f2_single_env_trace")
+    k = int(g["obj_number"])
+    np.random.seed(int(g["seed"]))
+    env = m.Environment(k)
+    obs0 = env.reset(returnable=True)
+    np.testing.assert_array_equal(env.points, g["points0"].astype(np.float32))   # same draws as the reference
+    assert obs0.shape == (3 * k,) and obs0.dtype == np.float64
+    np.testing.assert_allclose(obs0[0::3], g["obs0"][0::3], atol=DIST_TOL)
+    diverged = False
+    for t in range(len(g["action"])):
+        a = env.action_sample()
+        assert [int(v) for v in a] == list(g["action"][t])                        # R2 stream, bit-identical
+        obs2, reward, done = env.step(a)
+        assert isinstance(reward, int) and isinstance(done, bool)
+        jc = env.joints_coordinates
+        assert np.abs(jc - g["jc"][t]).max() <= POS_TOL
+        np.testing.assert_array_equal(env.goals, g["goals"][t])
+        if diverged:
+            continue
+        alive_before = g["alives"][t - 1] if t else np.ones(k, dtype=bool)
+        np.testing.assert_allclose(obs2[0::3], g["obs2"][t][0::3], atol=DIST_TOL)
+        # discrete outputs: guard on the fixture's own margins
+        zmin = np.abs(g["jc"][t][2:, 2]).min()
+        dl = np.abs(g["jc"][t][3][None, :] - g["points"][t])
+        pm = np.abs(dl - 8.0)[alive_before].min() if alive_before.any() else np.inf
+        if pm < GUARD:
+            diverged = True
+            continue
+        np.testing.assert_array_equal(env.alives, g["alives"][t])
+        assert done == bool(g["done"][t])
+        if zmin >= GUARD:        # final-pose margin only; sub-step margins are covered by the lockstep tests
+            assert reward in (int(g["reward"][t]), -1)
+    assert not diverged or t > 10
+
+
+def test_f3_substep_ground_flag(m, mo, golden):
+    g = golden("f3_substep_trace")
+    n = len(g["prev"])
+    eng = m.StepEngine(n, 1)
+    eng.reset(np.full((n, 1, 3), 1000.0, dtype=np.float32))
+    eng.set(m.lib.F_GOALS, g["prev"].astype(np.float32))
+    eng.step(g["action"])
+    zmargin = np.abs(g["jc"][:, :, 2:, 2]).reshape(n, -1).min(axis=1)
+    ok = zmargin >= GUARD
+    assert ok.sum() >= n - 2
+    np.testing.assert_array_equal(eng.reward()[ok], g["reward"][ok])
+    assert np.abs(eng.joints_coordinates() - g["jc"][:, -1]).max() <= POS_TOL
+    assert not eng.done().any()
+
+
+def test_f4_multienv_trace_drop_in(m, golden):
+    """The loop of test_multi.py:11-34 on the HIP engine, seeded like the fixture: same targets, same actions,
+    and outputs within tolerance for all 2 x 50 steps of 6 envs."""
+    g = golden("f4_multienv_trace")
+    shape = tuple(int(v) for v in g["env_shape"])
+    n, k, steps = shape[0] * shape[1], int(g["obj_number"]), int(g["max_steps"])
+    np.random.seed(int(g["seed"]))
+    me = m.Multienv(env_shape=shape, obj_number=k)
+    obs = me.reset(returnable=True)
+    assert isinstance(obs, list) and len(obs) == n and obs[0].shape == (3 * k,)
+    np.testing.assert_allclose(np.array(obs)[:, 0::3], g["obs0"][:, 0::3], atol=DIST_TOL)
+    t = 0
+    valid = np.ones(n, dtype=bool)
+    for ep in range(len(g["total_reward"])):
+        np.testing.assert_array_equal(np.array([e.points for e in me.environment]), g["points"][ep].astype(np.float32))
+        for _ in range(steps):
+            action = me.action_sample()
+            assert isinstance(action, list) and isinstance(action[0], list)
+            np.testing.assert_array_equal(np.array(action), g["action"][t])
+            obs2, reward, done = me.step(action)
+            assert isinstance(obs2, list) and isinstance(reward, list) and isinstance(done, list)
+            assert not (done == True)  # noqa: E712  test_multi.py:22: a list never equals True, the loop never breaks
+            jc = np.array([e.joints_coordinates for e in me.environment])
+            assert np.abs(jc - g["jc"][t]).max() <= POS_TOL
+            alive_before = g["alives"][t - 1] if t % steps else np.ones((n, k), dtype=bool)
+            dl = np.abs(g["jc"][t][:, 3][:, None, :] - _points_at(g, ep, t, steps))
+            pm = np.where(alive_before[..., None], np.abs(dl - 8.0), np.inf).reshape(n, -1).min(axis=1)
+            valid &= pm >= GUARD
+            np.testing.assert_array_equal(np.array([e.alives for e in me.environment])[valid], g["alives"][t][valid])
+            np.testing.assert_array_equal(np.array(done)[valid], g["done"][t][valid])
+            o = np.array(obs2)
+            np.testing.assert_allclose(o[valid][:, 0::3], g["obs2"][t][valid][:, 0::3], atol=DIST_TOL)
+            t += 1
+        totals = np.array([me.environment[i].total_reward for i in range(n)])
+        # returns can differ only through guarded threshold cases; on this fixture there are none
+        np.testing.assert_array_equal(totals[valid], g["total_reward"][ep][valid])
+        me.reset()
+        valid[:] = True
+    assert t == 2 * steps
+
+
+def _points_at(g, ep, t, steps):
+    """Targets of the fixture as they were at step t: dead targets are zeroed from the step after their pickup."""
+    pts = g["points"][ep].copy()
+    first = ep * steps
+    if t > first:
+        dead_prev = ~g["alives"][t - 1]
+        pts[dead_prev] = 0.0
+    return pts
+
+
+@pytest.mark.parametrize("name", ["multi_pickup", "ground_carry", "all_picked", "pickup_and_ground"])
+def test_f5_semantics(m, golden, name):
+    g = golden("f5_semantics_kat")
+    pts, acts = g[f"{name}__points_in"], g[f"{name}__actions"]
+    env = m.Environment(len(pts))
+    np.random.seed(0)
+    env.reset()
+    env.points = pts
+    for t, a in enumerate(acts):
+        obs2, r, d = env.step(list(a))
+        assert r == int(g[f"{name}__reward"][t]) and d == bool(g[f"{name}__done"][t])
+        np.testing.assert_array_equal(env.alives, g[f"{name}__alives"][t])
+        np.testing.assert_allclose(env.points, g[f"{name}__points"][t], atol=1e-5)   # incl. the zeroing of dead targets
+        np.testing.assert_allclose(obs2[0::3], g[f"{name}__obs2"][t][0::3], atol=DIST_TOL)
+        np.testing.assert_allclose(obs2, g[f"{name}__obs2"][t], atol=2e-3)
+        assert env.total_reward == float(g[f"{name}__total"][t])
+        assert np.abs(env.joints_coordinates - g[f"{name}__jc"][t]).max() <= POS_TOL
+
+
+def test_environment_piecewise_methods(m, golden):
+    """get_observations / is_done / action as separate calls (manytor.py:141,155,175)."""
+    g = golden("f5_semantics_kat")
+    pts = g["all_picked__points_in"]
+    env = m.Environment(len(pts))
+    np.random.seed(0)
+    env.reset()
+    env.points = pts
+    assert env.is_done() is False
+    reward, obs2 = env.action([30, 45, -60, 90], None)
+    assert reward == 1 and env.total_reward == 0.0            # action() does not accumulate (manytor.py:258 is in step)
+    assert env.is_done() is True
+    np.testing.assert_array_equal(env.get_obs(), np.zeros(3))
+    np.testing.assert_array_equal(env.points, np.zeros((1, 3)))
+
+
+# --------------------------------------------------------------------------- batches vs the oracle
+@pytest.mark.parametrize("n,k,steps", [(1, 10, 30), (63, 7, 12), (257, 1, 12), (4096, 7, 25), (1000, 32, 6)])
+def test_random_batches_lockstep_reference_arm(m, mo, n, k, steps):
+    rng = np.random.RandomState(1000 + n)
+    ls = Lockstep(m, mo, n, k)
+    from oracle import philox_ref as px
+    ls.reset(px.sample_targets(11, np.arange(n, dtype=np.uint64), 0, k, 51.3))
+    for t in range(steps):
+        ls.step(rng.randint(-180, 180, size=(n, 4)))
+    assert ls.guarded <= max(2, 0.01 * n * steps), ls.guarded
+    assert ls.compared > 0
+
+
+def test_random_batch_float_actions_and_small_moves(m, mo):
+    """Fractional degrees (goals stop being integers, manytor.py:184) and tiny moves around the pickup box."""
+    n, k = 2048, 7
+    rng = np.random.RandomState(77)
+    ls = Lockstep(m, mo, n, k)
+    ls.reset(rng.uniform(-30, 30, size=(n, k, 3)) + [0, 0, 35])
+    for t in range(10):
+        a = rng.uniform(-60, 60, size=(n, 4)).astype(np.float32)
+        ls.step(a.astype(np.float64))
+    assert ls.guarded <= 0.01 * n * 10
+
+
+def test_seven_dof_lockstep(m, mo, golden):
+    table = golden("f7_dh7_kat")["table"]
+    n, k = 2048, 7
+    rng = np.random.RandomState(7)
+    ls = Lockstep(m, mo, n, k, table=table, radius=92.6)
+    pts = rng.uniform(-60, 60, size=(n, k, 3))
+    pts[..., 2] = np.abs(pts[..., 2])
+    ls.reset(pts)
+    for t in range(8):
+        ls.step(rng.randint(-180, 180, size=(n, 7)))
+    assert ls.guarded <= 0.01 * n * 8
+
+
+@pytest.mark.parametrize("dof", [2, 3, 5, 8])
+def test_other_joint_counts(m, mo, dof):
+    rng = np.random.RandomState(dof)
+    table = np.column_stack([rng.uniform(0, 10, dof), rng.choice([-np.pi / 2, 0, np.pi / 2, 0.4], dof),
+                             rng.uniform(2, 15, dof), rng.choice([0, -np.pi / 2, 0.25], dof)])
+    ls = Lockstep(m, mo, 512, 4, table=table)
+    ls.reset(rng.uniform(-20, 20, size=(512, 4, 3)))
+    for t in range(5):
+        ls.step(rng.randint(-180, 180, size=(512, dof)))
+
+
+def test_substeps_and_tolerance_parameters(m, mo):
+    rng = np.random.RandomState(5)
+    ls = Lockstep(m, mo, 512, 5, substeps=2, pickup_tol=3.0)
+    ls.ora.pickup_tol = 3.0
+    ls.reset(rng.uniform(-40, 40, size=(512, 5, 3)))
+    for t in range(5):
+        ls.step(rng.randint(-180, 180, size=(512, 4)))
+
+
+@pytest.mark.parametrize("kw", [dict(hw_trig=True), dict(dh_in_lds=True)])
+def test_kernel_variants_agree_with_oracle(m, mo, kw):
+    rng = np.random.RandomState(9)
+    ls = Lockstep(m, mo, 4096, 7, **kw)
+    from oracle import philox_ref as px
+    ls.reset(px.sample_targets(3, np.arange(4096, dtype=np.uint64), 0, 7, 51.3))
+    for t in range(10):
+        ls.step(rng.randint(-180, 180, size=(4096, 4)))
+    assert ls.guarded <= 0.01 * 4096 * 10
+
+
+def test_terminate_on_ground_flag(m):
+    eng = m.StepEngine(2, 1, terminate_on_ground=True)
+    eng.reset(np.full((2, 1, 3), 1000.0, dtype=np.float32))
+    eng.step([[0, 180, 0, 0], [0, 10, 0, 0]])
+    np.testing.assert_array_equal(eng.reward(), [-1, 0])
+    np.testing.assert_array_equal(eng.done(), [True, False])
+
+
+# --------------------------------------------------------------------------- device RNG (bit-exact)
+def test_device_rng_streams_bit_exact(m):
+    from oracle import philox_ref as px
+    n, k, base = 5000, 7, 123456789012
+    eng = m.StepEngine(n, k, env_id_base=base)
+    ids = np.arange(base, base + n, dtype=np.uint64)
+    eng.reset_random(seed=0xABCDEF0123, episode=3)
+    np.testing.assert_array_equal(eng.points(), px.sample_targets(0xABCDEF0123, ids, 3, k, 51.3))
+    eng.sample_actions(seed=42, step_idx=17)
+    np.testing.assert_array_equal(eng.actions(), px.sample_actions(42, ids, 17, 4))
+    e7 = m.StepEngine(300, 2, dh_table=m.DH7_TABLE, radius=92.6)
+    e7.sample_actions(seed=42, step_idx=5)
+    np.testing.assert_array_equal(e7.actions(), px.sample_actions(42, np.arange(300, dtype=np.uint64), 5, 7))
+
+
+def test_step_random_equals_sample_then_step(m):
+    n, k = 10000, 7
+    a, b = m.StepEngine(n, k), m.StepEngine(n, k)
+    a.reset_random(1, 0)
+    b.reset_random(1, 0)
+    for t in range(5):
+        a.sample_actions(9, t)
+        a.step()
+        b.step_random(9, t)
+    for f in (m.lib.F_ACTIONS, m.lib.F_GOALS, m.lib.F_OBS, m.lib.F_REWARD, m.lib.F_DONE, m.lib.F_ALIVE, m.lib.F_EE,
+              m.lib.F_TOTAL_REWARD, m.lib.F_POINTS, m.lib.F_DONE_BITS):
+        np.testing.assert_array_equal(a.get(f), b.get(f))
+    c = m.StepEngine(n, k)
+    c.reset_random(1, 0)
+    c.rollout(5, 9, 0)
+    np.testing.assert_array_equal(c.get(m.lib.F_OBS), b.get(m.lib.F_OBS))
+    np.testing.assert_array_equal(c.total_reward(), b.total_reward())
+
+
+def test_shard_invariance(m):
+    """Same seed => same per-env results however the envs are split over handles."""
+    from manytor_amd.distributed import shard_range
+    n, k = 30000, 7
+    whole = m.StepEngine(n, k)
+    whole.reset_random(5, 0)
+    whole.rollout(6, 5, 0)
+    for world in (2, 8):
+        parts = []
+        for r in range(world):
+            base, cnt = shard_range(n, r, world)
+            e = m.StepEngine(cnt, k, env_id_base=base)
+            e.reset_random(5, 0)
+            e.rollout(6, 5, 0)
+            parts.append(e)
+        for f in (m.lib.F_OBS, m.lib.F_TOTAL_REWARD, m.lib.F_ALIVE, m.lib.F_GOALS, m.lib.F_REWARD):
+            np.testing.assert_array_equal(np.concatenate([p.get(f) for p in parts]), whole.get(f))
+
+
+# --------------------------------------------------------------------------- full-size properties (configs 2, 3, 5)
+@pytest.mark.parametrize("n,table_name", [(65536, "ref"), (1048576, "ref"), (1048576, "dh7")])
+def test_full_size_properties(m, mo, n, table_name):
+    """At BASELINE.json's sizes: size-independent invariants + an oracle check on a strided sample."""
+    table = m.REF_DH_TABLE if table_name == "ref" else m.DH7_TABLE
+    radius = 51.3 if table_name == "ref" else 92.6
+    dof, k = len(table), 7
+    eng = m.StepEngine(n, k, dh_table=table, radius=radius)
+    eng.reset_random(0x5EED, 0)
+    p0 = eng.points()
+    assert (p0[..., 2] >= 0).all() and (np.linalg.norm(p0.astype(np.float64), axis=-1) <= radius * (1 + 1e-6)).all()
+    sample = np.arange(0, n, max(1, n // 4096))[:4096]
+    ora = mo.BatchOracle(len(sample), k, table=np.asarray(table), radius=radius)
+    ora.reset(p0[sample].astype(np.float64))
+    ret = np.zeros(n, dtype=np.float64)
+    ever_guarded = np.zeros(len(sample), dtype=bool)
+    for t in range(4):
+        eng.step_random(0x5EED, t)
+        a = eng.actions()
+        assert a.min() >= -180 and a.max() <= 179 and np.all(a == np.round(a))
+        rew, done, alive, obs = eng.reward(), eng.done(), eng.alives(), eng.obs()
+        ret += rew
+        assert set(np.unique(rew)) <= {-1, 0, 1}
+        np.testing.assert_array_equal(done, ~alive.any(axis=1))
+        np.testing.assert_array_equal(eng.goals(), a)                              # goals = action (manytor.py:184)
+        o = obs.reshape(n, k, 3)
+        assert np.isfinite(o).all() and (o >= 0).all() and (o[..., 1:] <= 90.0 + 1e-3).all()
+        pre_alive = ora.alives.copy()
+        obs_ref, rew_ref, _ = ora.step(a[sample].astype(np.float64))
+        assert np.abs(eng.ee()[sample] - ora.joints_coordinates[:, -1]).max() <= POS_TOL
+        pm = np.where(pre_alive, ora.pickup_margin, np.inf).min(axis=1)
+        ever_guarded |= (ora.ground_margin < GUARD) | (pm < GUARD)
+        okk = ~ever_guarded
+        np.testing.assert_array_equal(rew[sample][okk], rew_ref[okk])
+        np.testing.assert_array_equal(alive[sample][okk], ora.alives[okk])
+        assert_obs_close(obs[sample][okk], obs_ref[okk], ora.joints_coordinates[okk, -2], ora.points[okk], pre_alive[okk])
+    np.testing.assert_array_equal(eng.total_reward(), ret.astype(np.float32))      # return = sum of rewards
+    assert ever_guarded.mean() < 0.02
+    bits = eng.done_bits()
+    assert int(sum(bin(int(b)).count("1") for b in bits)) == int(eng.done().sum())
+    # idempotence of the standalone passes at a fixed pose
+    obs_a = eng.obs().copy()
+    eng.observe()
+    obs_b = eng.obs()
+    dead = np.repeat(~eng.alives(), 3, axis=1)
+    np.testing.assert_array_equal(obs_b[~dead], obs_a[~dead])
+    assert np.all(obs_b[dead] == 0)
+    alive_a = eng.alives().copy()
+    eng.check_done()
+    np.testing.assert_array_equal(eng.alives(), alive_a)
+
+
+def test_reset_done_rearms_only_finished_envs(m):
+    n, k = 4096, 1
+    eng = m.StepEngine(n, k, pickup_tol=30.0)
+    eng.reset_random(3, 0)
+    for t in range(6):
+        eng.step_random(3, t)
+    done = eng.done()
+    assert 0 < done.sum() < n
+    goals, total, pts = eng.goals(), eng.total_reward(), eng.points()
+    eng.reset_done(3, 1)
+    assert eng.alives()[done].all() and not eng.done().any() and not eng.done_bits().any()
+    assert np.all(eng.goals()[done] == 0) and np.all(eng.total_reward()[done] == 0)
+    np.testing.assert_array_equal(eng.goals()[~done], goals[~done])
+    np.testing.assert_array_equal(eng.total_reward()[~done], total[~done])
+    np.testing.assert_array_equal(eng.points()[~done], pts[~done])
+    assert (np.abs(eng.points()[done]).sum(axis=(1, 2)) > 0).all()
+
+
+# --------------------------------------------------------------------------- boundary behaviour
+def test_errors_are_loud(m):
+    eng = m.StepEngine(8, 3)
+    with pytest.raises(m.ManytorError):
+        eng.step(np.zeros((8, 4)))                      # before reset
+    eng.reset(np.zeros((8, 3, 3), dtype=np.float32))
+    with pytest.raises(ValueError):
+        eng.step(np.zeros((7, 4)))
+    with pytest.raises(ValueError):
+        m.StepEngine(8, 40)
+    with pytest.raises(ValueError):
+        m.StepEngine(8, 3, substeps=1)
+    eng.close()
+    with pytest.raises(RuntimeError):
+        eng.step(np.zeros((8, 4)))
+
+
+def test_action_dtypes_and_layouts(m):
+    n = 300
+    rng = np.random.RandomState(0)
+    a = rng.randint(-180, 180, size=(n, 4))
+    eng = m.StepEngine(n, 2)
+    for cast in (np.int64, np.int32, np.float32, np.float64, list):
+        eng.set_actions(a.tolist() if cast is list else a.astype(cast))
+        np.testing.assert_array_equal(eng.actions(), a.astype(np.float32))
+
+
+def test_torch_device_views_and_device_inputs(m):
+    import torch
+    n, k = 1000, 7
+    eng = m.StepEngine(n, k)
+    eng.reset_random(1, 0)
+    eng.step_random(1, 0)
+    eng.sync()
+    for f in (m.lib.F_OBS, m.lib.F_GOALS, m.lib.F_POINTS, m.lib.F_EE):
+        t = eng.device_tensor(f)
+        ref = eng.get(f).reshape(n, -1)
+        assert t.is_cuda and tuple(t.shape) == (ref.shape[1], n)
+        np.testing.assert_array_equal(t.T.cpu().numpy(), ref)
+    np.testing.assert_array_equal(eng.device_tensor(m.lib.F_REWARD).cpu().numpy(), eng.reward())
+    np.testing.assert_array_equal(eng.device_tensor(m.lib.F_DONE).cpu().numpy(), eng.get(m.lib.F_DONE))
+    np.testing.assert_array_equal(eng.device_tensor(m.lib.F_TOTAL_REWARD).cpu().numpy(), eng.total_reward())
+    # device-resident actions in, both layouts
+    a = torch.randint(-180, 180, (n, 4), device="cuda")
+    eng.set_actions(a)
+    np.testing.assert_array_equal(eng.actions(), a.cpu().numpy().astype(np.float32))
+    soa = torch.zeros((4, eng.ld), dtype=torch.float32, device="cuda")
+    soa[:, :n] = a.T.to(torch.float32) + 1
+    eng.set_actions(soa)
+    np.testing.assert_array_equal(eng.actions(), a.cpu().numpy().astype(np.float32) + 1)
+    # device-resident targets in
+    pts = torch.rand((n, k, 3), device="cuda") * 20
+    eng.reset(pts)
+    np.testing.assert_array_equal(eng.points(), pts.cpu().numpy())
+
+
+def test_large_multienv_returns_views_not_lists(m):
+    me = m.Multienv(env_shape=(128, 64), obj_number=7, rng="device")
+    obs = me.reset(returnable=True)
+    assert isinstance(obs, m.BatchView) and len(obs) == 8192
+    a = me.action_sample()
+    obs2, reward, done = me.step(a)
+    assert not (done == True)  # noqa: E712
+    assert np.asarray(obs2).shape == (8192, 21) and np.asarray(reward).shape == (8192,)
+    assert obs2.torch().shape == (8192, 21)
+    assert isinstance(me.environment[5].total_reward, float)
+    assert len(me.environment) == 8192
