@@ -83,6 +83,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--hw-trig", action="store_true")
     ap.add_argument("--dh-in-lds", action="store_true")
+    ap.add_argument("--direct-trig", action="store_true")
+    ap.add_argument("--no-specialize", action="store_true")
     args = ap.parse_args()
 
     import torch
@@ -105,7 +107,8 @@ def main():
     table = m.REF_DH_TABLE if args.dof == 4 else m.DH7_TABLE
     radius = 51.3 if args.dof == 4 else 92.6
     eng = m.StepEngine(n_local, args.targets, dh_table=table, radius=radius, device=local_rank, env_id_base=base,
-                       hw_trig=args.hw_trig, dh_in_lds=args.dh_in_lds)
+                       hw_trig=args.hw_trig, dh_in_lds=args.dh_in_lds, direct_trig=args.direct_trig,
+                       specialize=not args.no_specialize)
     eng.use_torch_stream()                                      # engine launches and torch/RCCL share one ordering
     returns = eng.device_tensor(m.lib.F_TOTAL_REWARD)
     L = args.episode_len
@@ -158,6 +161,12 @@ def main():
         launches = sum(s for _, s in kernel_ms)
         avg_kernel_s = sum(ms for ms, _ in kernel_ms) / launches / 1e3
         achieved = bpe * n_local / avg_kernel_s / 1e9
+        trig = 2 if args.hw_trig else (1 if args.direct_trig else 0)
+        static = not (args.no_specialize or args.dh_in_lds)
+        table_name = ("Ref4Table" if args.dof == 4 else "Dh7Table") if static else f"RtTable<{args.dof}>"
+        variant = "+".join(v for v, on in (("recurrence", trig == 0), ("direct_trig", trig == 1), ("hw_trig", trig == 2),
+                                           ("static_table", static), ("runtime_table", not static),
+                                           ("dh_in_lds", args.dh_in_lds)) if on)
         workload = f"{n_local} arms/GPU x {world} GPU, {args.dof}-DoF DH chain, K={args.targets} targets, " \
                    f"25 sub-steps, random integer-degree actions drawn in-kernel, episode {L} steps"
         out = {
@@ -167,12 +176,12 @@ def main():
             "config": {"workload": workload, "envs_per_gpu": n_local, "envs_total": n_total, "dof": args.dof,
                        "targets": args.targets, "substeps": 25, "episode_len": L,
                        "collective": "RCCL all-gather of returns per episode" if world > 1 else "none (1 GPU)",
-                       "kernel_variant": "hw_trig" if args.hw_trig else ("dh_in_lds" if args.dh_in_lds else "default")},
+                       "kernel_variant": variant},
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": load_traffic(f"d{args.dof}_k{args.targets}_n{n_local}"),
-                "kernel": f"step_kernel<{args.dof}, sample, {'1' if args.hw_trig else ('2' if args.dh_in_lds else '0')}>",
+                "kernel": f"step_kernel<{table_name}, sample=true, trig={trig}, lds={str(args.dh_in_lds).lower()}>",
                 "bytes_per_env_step": bpe, "avg_kernel_us": avg_kernel_s * 1e6,
             },
         }

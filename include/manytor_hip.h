@@ -78,8 +78,11 @@ typedef enum mt_layout { MT_ENV_MAJOR = 0, MT_SOA = 1 } mt_layout;
 
 /* Engine flags (mt_config.flags). Defaults (0) reproduce the reference. */
 #define MT_FLAG_TERMINATE_ON_GROUND 0x1u /* done |= ground hit (README.md:44 intent; NOT what manytor.py:170 does) */
-#define MT_FLAG_HW_TRIG 0x2u             /* v_sin/v_cos for the intermediate sub-steps (ground flag only)          */
-#define MT_FLAG_DH_IN_LDS 0x4u           /* stage the DH constants in LDS instead of SGPRs (measured variant)     */
+#define MT_FLAG_HW_TRIG 0x2u             /* v_sin/v_cos at every interior sub-step instead of the recurrence      */
+#define MT_FLAG_DH_IN_LDS 0x4u           /* stage the DH constants in LDS instead of SGPRs (measured variant;      */
+                                         /* implies the runtime-table kernel)                                      */
+#define MT_FLAG_DIRECT_TRIG 0x8u         /* polynomial sincos at every interior sub-step (no recurrence)           */
+#define MT_FLAG_NO_SPECIALIZE 0x10u      /* never use a compile-time DH table even if the table matches one        */
 
 /* Constructor arguments.  Replaces Environment.__init__/Multienv.__init__
  * (manytor.py:130-139, :77-82) plus the literals the reference hard-codes:

@@ -33,6 +33,8 @@ ENV_MAJOR, SOA = 0, 1
 FLAG_TERMINATE_ON_GROUND = 0x1
 FLAG_HW_TRIG = 0x2
 FLAG_DH_IN_LDS = 0x4
+FLAG_DIRECT_TRIG = 0x8
+FLAG_NO_SPECIALIZE = 0x10
 
 
 class ManytorError(RuntimeError):

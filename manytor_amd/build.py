@@ -39,6 +39,8 @@ def build_library(force: bool = False, verbose: bool = False, extra_flags=()) ->
     cmd = [
         _hipcc(), "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-fvisibility=hidden",
         "-I", INCLUDE, "-Wall", "-Wno-unused-function",
+        # let x*0 and x+0 fold (static DH tables); no NaN/inf/-0 is ever produced on the step path
+        "-fno-signed-zeros", "-ffinite-math-only",
         *extra_flags,
         *[os.path.join(CSRC, s) for s in SOURCES],
         "-o", LIB_PATH + ".tmp",

@@ -39,7 +39,9 @@ struct mt_engine {
   size_t staging_bytes = 0;
   StepArgs args{};
   bool is_reset = false;
-  int variant = 0;
+  int trig = 0;          // 0 recurrence, 1 polynomial sincos per sub-step, 2 hardware trig per sub-step
+  bool lds_table = false;
+  int static_kind = 0;   // 0 runtime table, 1 Ref4Table, 2 Dh7Table
   std::string err;
 };
 
@@ -102,25 +104,60 @@ int ensure_staging(mt_handle h, size_t bytes) {
   return MT_OK;
 }
 
-// ---- kernel dispatch on the compile-time joint count -------------------------------------------
+// ---- kernel dispatch ---------------------------------------------------------------------------
+// static_kind: 0 = runtime table (RtTable<D>), 1 = Ref4Table, 2 = Dh7Table
+template <class Tbl>
+bool table_matches(const DhConst& t, int dof) {
+  if (dof != Tbl::D) return false;
+  for (int j = 0; j < dof; ++j)
+    if (t.a[j] != Tbl::a(j) || t.d[j] != Tbl::d(j) || t.sa[j] != Tbl::sa(j) || t.ca[j] != Tbl::ca(j) ||
+        t.off_deg[j] != Tbl::off(j))
+      return false;
+  return true;
+}
+
+int match_static(const DhConst& t, int dof) {
+  if (table_matches<Ref4Table>(t, dof)) return 1;
+  if (table_matches<Dh7Table>(t, dof)) return 2;
+  return 0;
+}
+
+template <class Tbl, bool LDS_OK>
+void launch_step_t(mt_handle h, bool sample) {
+  const dim3 g = grid_for(h->n), b(kBlock);
+#define MT_LAUNCH_STEP(SAMPLE_, TRIG_, LDS_) \
+  hipLaunchKernelGGL((step_kernel<Tbl, SAMPLE_, TRIG_, LDS_>), g, b, 0, h->stream, h->args)
+  if (LDS_OK && h->lds_table) {
+    if constexpr (LDS_OK) {
+      if (sample) MT_LAUNCH_STEP(true, 0, true); else MT_LAUNCH_STEP(false, 0, true);
+    }
+    return;
+  }
+  switch (h->trig) {
+    case 1: if (sample) MT_LAUNCH_STEP(true, 1, false); else MT_LAUNCH_STEP(false, 1, false); break;
+    case 2: if (sample) MT_LAUNCH_STEP(true, 2, false); else MT_LAUNCH_STEP(false, 2, false); break;
+    default: if (sample) MT_LAUNCH_STEP(true, 0, false); else MT_LAUNCH_STEP(false, 0, false); break;
+  }
+#undef MT_LAUNCH_STEP
+}
+
 template <int D>
 void launch_step_d(mt_handle h, bool sample) {
-  const dim3 g = grid_for(h->n), b(kBlock);
-  const int v = h->variant;
-  if (sample) {
-    if (v == 1)
-      hipLaunchKernelGGL((step_kernel<D, true, 1>), g, b, 0, h->stream, h->args);
-    else if (v == 2)
-      hipLaunchKernelGGL((step_kernel<D, true, 2>), g, b, 0, h->stream, h->args);
-    else
-      hipLaunchKernelGGL((step_kernel<D, true, 0>), g, b, 0, h->stream, h->args);
-  } else {
-    if (v == 1)
-      hipLaunchKernelGGL((step_kernel<D, false, 1>), g, b, 0, h->stream, h->args);
-    else if (v == 2)
-      hipLaunchKernelGGL((step_kernel<D, false, 2>), g, b, 0, h->stream, h->args);
-    else
-      hipLaunchKernelGGL((step_kernel<D, false, 0>), g, b, 0, h->stream, h->args);
+  launch_step_t<RtTable<D>, true>(h, sample);
+}
+
+void launch_step(mt_handle h, bool sample) {
+  if (h->static_kind == 1) return launch_step_t<Ref4Table, false>(h, sample);
+  if (h->static_kind == 2) return launch_step_t<Dh7Table, false>(h, sample);
+  switch (h->D) {
+    case 2: return launch_step_d<2>(h, sample);
+    case 3: return launch_step_d<3>(h, sample);
+    case 4: return launch_step_d<4>(h, sample);
+    case 5: return launch_step_d<5>(h, sample);
+    case 6: return launch_step_d<6>(h, sample);
+    case 7: return launch_step_d<7>(h, sample);
+    case 8: return launch_step_d<8>(h, sample);
+    default: return;
   }
 }
 
@@ -249,7 +286,8 @@ int mt_create(mt_handle* out, const mt_config* cfg) {
   h->ld = (int64_t)align_up((size_t)cfg->n_envs, 256);
   h->D = cfg->dof;
   h->K = cfg->n_targets;
-  h->variant = (cfg->flags & MT_FLAG_DH_IN_LDS) ? 2 : ((cfg->flags & MT_FLAG_HW_TRIG) ? 1 : 0);
+  h->trig = (cfg->flags & MT_FLAG_HW_TRIG) ? 2 : ((cfg->flags & MT_FLAG_DIRECT_TRIG) ? 1 : 0);
+  h->lds_table = (cfg->flags & MT_FLAG_DH_IN_LDS) != 0;
 
   auto bail = [&](int code, const std::string& msg) {
     g_last_error = msg;
@@ -310,6 +348,7 @@ int mt_create(mt_handle* out, const mt_config* cfg) {
   a.inv_sm1 = 1.0f / (float)(cfg->substeps - 1);
   a.flags = cfg->flags;
   a.dh = make_dh(cfg->dh_table, h->D);
+  h->static_kind = (cfg->flags & (MT_FLAG_NO_SPECIALIZE | MT_FLAG_DH_IN_LDS)) ? 0 : match_static(a.dh, h->D);
 #undef MT_HIP_C
   *out = h;
   return MT_OK;
@@ -452,7 +491,7 @@ int mt_step(mt_handle h) {
   MT_REQUIRE(nullptr, h != nullptr, "handle is NULL");
   if (!h->is_reset) return fail(h, MT_ERR_STATE, "mt_step before mt_reset / mt_reset_random");
   MT_HIP(h, hipSetDevice(h->cfg.device));
-  MT_DISPATCH_D(h->D, launch_step_d, h, false);
+  launch_step(h, false);
   return check_launch(h, "step_kernel");
 }
 
@@ -463,7 +502,7 @@ int mt_step_random(mt_handle h, uint64_t seed, uint32_t step_idx) {
   h->args.seed_lo = (uint32_t)seed;
   h->args.seed_hi = (uint32_t)(seed >> 32);
   h->args.major = step_idx;
-  MT_DISPATCH_D(h->D, launch_step_d, h, true);
+  launch_step(h, true);
   return check_launch(h, "step_kernel");
 }
 

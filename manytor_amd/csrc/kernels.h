@@ -55,15 +55,60 @@ struct StepArgs {
 };
 
 // ---------------------------------------------------------------------------
+// DH table views.  The chain code below is written once against this
+// interface; `RtTable` reads the per-launch constants (SGPRs or LDS), the
+// static tables are compile-time constants, so after unrolling every product
+// with a 0 / +-1 entry disappears and the chain collapses to the arm's closed
+// form (for the reference arm: z_elbow = d0 + d2 c1, z_ee = z_elbow +
+// a3 (c1 s3' ... )).  The host picks a static table only
+// when the configured table matches it exactly (engine.hip: match_static).
+// ---------------------------------------------------------------------------
+template <int D_>
+struct RtTable {
+  static constexpr int D = D_;
+  const DhConst& c;
+  __device__ __forceinline__ float a(int j) const { return c.a[j]; }
+  __device__ __forceinline__ float d(int j) const { return c.d[j]; }
+  __device__ __forceinline__ float sa(int j) const { return c.sa[j]; }
+  __device__ __forceinline__ float ca(int j) const { return c.ca[j]; }
+  __device__ __forceinline__ float off(int j) const { return c.off_deg[j]; }
+};
+
+#define MT_SEL8(j, v0, v1, v2, v3, v4, v5, v6, v7) \
+  ((j) == 0 ? (v0) : (j) == 1 ? (v1) : (j) == 2 ? (v2) : (j) == 3 ? (v3) : (j) == 4 ? (v4) : (j) == 5 ? (v5) : (j) == 6 ? (v6) : (v7))
+
+// The reference arm, manytor.py:42-48: rows (a, alpha, d, theta offset) =
+// (0,-pi/2,4.3,0) (0,pi/2,0,0) (0,-pi/2,24.3,0) (27,pi/2,0,-pi/2).
+struct Ref4Table {
+  static constexpr int D = 4;
+  __host__ __device__ static constexpr float a(int j) { return MT_SEL8(j, 0.f, 0.f, 0.f, 27.0f, 0.f, 0.f, 0.f, 0.f); }
+  __host__ __device__ static constexpr float d(int j) { return MT_SEL8(j, 4.3f, 0.f, 24.3f, 0.f, 0.f, 0.f, 0.f, 0.f); }
+  __host__ __device__ static constexpr float sa(int j) { return MT_SEL8(j, -1.f, 1.f, -1.f, 1.f, 0.f, 0.f, 0.f, 0.f); }
+  __host__ __device__ static constexpr float ca(int j) { return MT_SEL8(j, 0.f, 0.f, 0.f, 0.f, 1.f, 1.f, 1.f, 1.f); }
+  __host__ __device__ static constexpr float off(int j) { return MT_SEL8(j, 0.f, 0.f, 0.f, -90.f, 0.f, 0.f, 0.f, 0.f); }
+};
+
+// The 7-joint table of BASELINE.json configs[4] (manytor_amd/engine.py DH7_TABLE, fixture F7).
+struct Dh7Table {
+  static constexpr int D = 7;
+  __host__ __device__ static constexpr float a(int j) { return MT_SEL8(j, 0.f, 0.f, 4.5f, -4.5f, 0.f, 8.8f, 0.f, 0.f); }
+  __host__ __device__ static constexpr float d(int j) { return MT_SEL8(j, 34.0f, 0.f, 40.0f, 0.f, 40.0f, 0.f, 12.6f, 0.f); }
+  __host__ __device__ static constexpr float sa(int j) { return MT_SEL8(j, -1.f, 1.f, 1.f, -1.f, -1.f, 1.f, 0.f, 0.f); }
+  __host__ __device__ static constexpr float ca(int j) { return MT_SEL8(j, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 1.f, 1.f); }
+  __host__ __device__ static constexpr float off(int j) { return MT_SEL8(j, 0.f, 0.f, 0.f, 0.f, 0.f, -90.f, 0.f, 0.f); }
+};
+
+// ---------------------------------------------------------------------------
 // DH chain.  R = [X Y Z] (columns), p = origin.  One joint:
 //   X' = X c + Y s ;  T = Y c - X s ;  Y' = T ca + Z sa ;  Z' = Z ca - T sa
 //   p' = p + a X' + d Z
 // which is R' = R * M(theta, alpha), p' = p + R * (a c, a s, d) for the matrix
 // M of manytor.py:28-31.
 // ---------------------------------------------------------------------------
-template <int D>
-__device__ __forceinline__ void chain_all(const float (&s)[D], const float (&c)[D], const DhConst& t,
-                                          float (&p)[D][3]) {
+template <class Tbl>
+__device__ __forceinline__ void chain_all(const float (&s)[Tbl::D], const float (&c)[Tbl::D], const Tbl& t,
+                                          float (&p)[Tbl::D][3]) {
+  constexpr int D = Tbl::D;
   float X[3] = {1.f, 0.f, 0.f}, Y[3] = {0.f, 1.f, 0.f}, Z[3] = {0.f, 0.f, 1.f};
   float o[3] = {0.f, 0.f, 0.f};
 #pragma unroll
@@ -72,10 +117,10 @@ __device__ __forceinline__ void chain_all(const float (&s)[D], const float (&c)[
     for (int q = 0; q < 3; ++q) {
       const float nx = X[q] * c[j] + Y[q] * s[j];
       const float tt = Y[q] * c[j] - X[q] * s[j];
-      o[q] += t.a[j] * nx + t.d[j] * Z[q];
+      o[q] += t.a(j) * nx + t.d(j) * Z[q];
       X[q] = nx;
-      Y[q] = tt * t.ca[j] + Z[q] * t.sa[j];
-      Z[q] = Z[q] * t.ca[j] - tt * t.sa[j];
+      Y[q] = tt * t.ca(j) + Z[q] * t.sa(j);
+      Z[q] = Z[q] * t.ca(j) - tt * t.sa(j);
       p[j][q] = o[q];
     }
   }
@@ -84,19 +129,20 @@ __device__ __forceinline__ void chain_all(const float (&s)[D], const float (&c)[
 // z components only, of the frames after D-1 and after D joints: what the
 // ground test of manytor.py:191 needs.  Joint 0's angle drops out (the z row of
 // the identity is (0,0,1)), which the compiler sees after unrolling.
-template <int D>
-__device__ __forceinline__ void chain_z(const float (&s)[D], const float (&c)[D], const DhConst& t, float& z_obs,
+template <class Tbl>
+__device__ __forceinline__ void chain_z(const float (&s)[Tbl::D], const float (&c)[Tbl::D], const Tbl& t, float& z_obs,
                                         float& z_ee) {
+  constexpr int D = Tbl::D;
   float x = 0.f, y = 0.f, z = 1.f, o = 0.f;
   z_obs = 0.f;
 #pragma unroll
   for (int j = 0; j < D; ++j) {
     const float nx = x * c[j] + y * s[j];
     const float tt = y * c[j] - x * s[j];
-    o += t.a[j] * nx + t.d[j] * z;
+    o += t.a(j) * nx + t.d(j) * z;
     x = nx;
-    y = tt * t.ca[j] + z * t.sa[j];
-    z = z * t.ca[j] - tt * t.sa[j];
+    y = tt * t.ca(j) + z * t.sa(j);
+    z = z * t.ca(j) - tt * t.sa(j);
     if (j == D - 2 && D > 2) z_obs = o;
   }
   z_ee = o;
@@ -120,21 +166,42 @@ __device__ __forceinline__ bool within_box(const float (&e)[3], float x, float y
 
 // ---------------------------------------------------------------------------
 // step: Environment.step() for all envs (manytor.py:255-260 + :175-213).
+//   Tbl    : RtTable<D> (any table, constants per launch) or a static table
 //   SAMPLE : draw the action in-kernel (== sample_actions_kernel then step)
-//   VARIANT: 0 polynomial trig, DH constants in SGPRs
-//            1 hardware v_sin/v_cos for the S-1 intermediate sub-steps
-//            2 DH constants staged in LDS
+//   TRIG   : how sin/cos of the S-2 interior sub-step poses are obtained
+//            0 angle-addition recurrence: the poses are g + k*delta, so
+//              (c,s)_{k+1} = (c,s)_k rotated by delta -- 4 FMA-class ops per joint
+//              instead of a sincos.  Run forward from the previous pose (k = 0,
+//              exact) and backward from the action (k = S-1, exact) to the middle,
+//              which halves the drift (<= 12 rotations, < 1e-4 in z, inside the
+//              1e-3 guard band of the ground flag) and gives two independent
+//              dependency chains per iteration.
+//            1 polynomial sincos at every sub-step (reference-shaped, slowest)
+//            2 hardware v_sin_f32/v_cos_f32 at every interior sub-step
+//   LDS    : stage the runtime DH constants in LDS instead of SGPRs (measured
+//            variant; BASELINE.json's north_star asks for the comparison)
+// The first and last pose are always evaluated with the polynomial sincos.
 // ---------------------------------------------------------------------------
-template <int D, bool SAMPLE, int VARIANT>
+template <class Tbl>
+struct TableMaker {
+  static __device__ __forceinline__ Tbl make(const DhConst&) { return Tbl{}; }
+};
+template <int D>
+struct TableMaker<RtTable<D>> {
+  static __device__ __forceinline__ RtTable<D> make(const DhConst& c) { return RtTable<D>{c}; }
+};
+
+template <class Tbl, bool SAMPLE, int TRIG, bool LDS>
 __global__ __launch_bounds__(kBlock) void step_kernel(const StepArgs a) {
+  constexpr int D = Tbl::D;
   __shared__ DhConst sh;
-  if (VARIANT == 2) {
+  if (LDS) {
     const float* src = reinterpret_cast<const float*>(&a.dh);
     float* dst = reinterpret_cast<float*>(&sh);
     if (threadIdx.x < sizeof(DhConst) / sizeof(float)) dst[threadIdx.x] = src[threadIdx.x];
     __syncthreads();
   }
-  const DhConst& t = (VARIANT == 2) ? sh : a.dh;
+  const Tbl t = TableMaker<Tbl>::make(LDS ? sh : a.dh);
 
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= a.n) return;
@@ -161,37 +228,17 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const StepArgs a) {
   }
 
   // route[k] = goals + k * (action - goals) / (S-1), route[S-1] = action (np.linspace, manytor.py:182)
-  float gq[D], st[D];
+  float st[D];
 #pragma unroll
-  for (int j = 0; j < D; ++j) {
-    st[j] = (act[j] - g[j]) * a.inv_sm1;
-    gq[j] = g[j] + t.off_deg[j];
-  }
+  for (int j = 0; j < D; ++j) st[j] = (act[j] - g[j]) * a.inv_sm1;
 
   bool ground = false;
-  float s[D], c[D];
-  s[0] = 0.f;
-  c[0] = 1.f;
-  for (int k = 0; k < a.S - 1; ++k) {  // sub-steps 0..S-2: only the ground flag is consumed (manytor.py:191)
-    const float fk = (float)k;
+  float zo, ze;
+  // k = S-1: the action itself, full chain (positions are consumed below)
+  float sA[D], cA[D], p[D][3];
 #pragma unroll
-    for (int j = 1; j < D; ++j) {
-      const float pose = __builtin_fmaf(fk, st[j], gq[j]);
-      if (VARIANT == 1)
-        sincos_deg_hw(pose, s[j], c[j]);
-      else
-        sincos_deg(pose, s[j], c[j]);
-    }
-    float zo, ze;
-    chain_z<D>(s, c, t, zo, ze);
-    ground |= (zo < 0.f) | (ze < 0.f);
-  }
-
-  // final pose = the action itself
-  float p[D][3];
-#pragma unroll
-  for (int j = 0; j < D; ++j) sincos_deg(act[j] + t.off_deg[j], s[j], c[j]);
-  chain_all<D>(s, c, t, p);
+  for (int j = 0; j < D; ++j) sincos_deg(act[j] + t.off(j), sA[j], cA[j]);
+  chain_all<Tbl>(sA, cA, t, p);
   float el[3], e[3];
 #pragma unroll
   for (int q = 0; q < 3; ++q) {
@@ -199,6 +246,70 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const StepArgs a) {
     e[q] = p[D - 1][q];
   }
   ground |= (el[2] < 0.f) | (e[2] < 0.f);
+
+  // k = 0: the previous pose (manytor.py:182-192 evaluates it again: a pose left below ground costs -1 twice)
+  float sF[D], cF[D];
+  sF[0] = 0.f;
+  cF[0] = 1.f;
+#pragma unroll
+  for (int j = 1; j < D; ++j) sincos_deg(g[j] + t.off(j), sF[j], cF[j]);
+  chain_z<Tbl>(sF, cF, t, zo, ze);
+  ground |= (zo < 0.f) | (ze < 0.f);
+
+  if (TRIG == 0) {
+    float sd[D], cd[D];
+    sd[0] = 0.f;
+    cd[0] = 1.f;
+#pragma unroll
+    for (int j = 1; j < D; ++j) sincos_deg(st[j], sd[j], cd[j]);
+    float sB[D], cB[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      sB[j] = sA[j];
+      cB[j] = cA[j];
+    }
+    sB[0] = 0.f;
+    cB[0] = 1.f;
+    const int nf = (a.S - 1) / 2;   // forward poses k = 1..nf
+    const int nb = a.S - 2 - nf;    // backward poses k = S-2..nf+1   (nb = nf or nf-1)
+    for (int it = 1; it <= nf; ++it) {
+#pragma unroll
+      for (int j = 1; j < D; ++j) {  // rotate by +delta
+        const float c2 = cF[j] * cd[j] - sF[j] * sd[j];
+        sF[j] = sF[j] * cd[j] + cF[j] * sd[j];
+        cF[j] = c2;
+      }
+      chain_z<Tbl>(sF, cF, t, zo, ze);
+      ground |= (zo < 0.f) | (ze < 0.f);
+      if (it <= nb) {
+#pragma unroll
+        for (int j = 1; j < D; ++j) {  // rotate by -delta
+          const float c2 = cB[j] * cd[j] + sB[j] * sd[j];
+          sB[j] = sB[j] * cd[j] - cB[j] * sd[j];
+          cB[j] = c2;
+        }
+        chain_z<Tbl>(sB, cB, t, zo, ze);
+        ground |= (zo < 0.f) | (ze < 0.f);
+      }
+    }
+  } else {
+    float gq[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) gq[j] = g[j] + t.off(j);
+    for (int k = 1; k < a.S - 1; ++k) {
+      const float fk = (float)k;
+#pragma unroll
+      for (int j = 1; j < D; ++j) {
+        const float pose = __builtin_fmaf(fk, st[j], gq[j]);
+        if (TRIG == 2)
+          sincos_deg_hw(pose, sF[j], cF[j]);
+        else
+          sincos_deg(pose, sF[j], cF[j]);
+      }
+      chain_z<Tbl>(sF, cF, t, zo, ze);
+      ground |= (zo < 0.f) | (ze < 0.f);
+    }
+  }
 
   // obs2 (before pickup, manytor.py:204) and pickup (manytor.py:206) per target
   const uint32_t am = a.alive[i];
@@ -288,7 +399,7 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(const StepArgs a, float r
       a.goals[j * ld + i] = 0.f;
       sincos_deg(a.dh.off_deg[j], s[j], c[j]);
     }
-    chain_all<D>(s, c, a.dh, p);  // joints_coordinates at the zero pose, manytor.py:224-225
+    chain_all<RtTable<D>>(s, c, RtTable<D>{a.dh}, p);  // joints_coordinates at the zero pose, manytor.py:224-225
 #pragma unroll
     for (int q = 0; q < 3; ++q) a.ee[q * ld + i] = p[D - 1][q];
     a.total_reward[i] = 0.f;
@@ -336,7 +447,7 @@ __global__ __launch_bounds__(kBlock) void observe_kernel(const StepArgs a) {
   float s[D], c[D], p[D][3];
 #pragma unroll
   for (int j = 0; j < D; ++j) sincos_deg(a.goals[j * ld + i] + a.dh.off_deg[j], s[j], c[j]);
-  chain_all<D>(s, c, a.dh, p);
+  chain_all<RtTable<D>>(s, c, RtTable<D>{a.dh}, p);
   float el[3];
 #pragma unroll
   for (int q = 0; q < 3; ++q) el[q] = (D > 2) ? p[D - 2][q] : 0.f;
@@ -370,7 +481,7 @@ __global__ __launch_bounds__(kBlock) void check_done_kernel(const StepArgs a) {
   float s[D], c[D], p[D][3];
 #pragma unroll
   for (int j = 0; j < D; ++j) sincos_deg(a.goals[j * ld + i] + a.dh.off_deg[j], s[j], c[j]);
-  chain_all<D>(s, c, a.dh, p);
+  chain_all<RtTable<D>>(s, c, RtTable<D>{a.dh}, p);
   float e[3];
 #pragma unroll
   for (int q = 0; q < 3; ++q) e[q] = p[D - 1][q];
@@ -396,7 +507,7 @@ __global__ __launch_bounds__(kBlock) void joints_kernel(const StepArgs a, float*
   float s[D], c[D], p[D][3];
 #pragma unroll
   for (int j = 0; j < D; ++j) sincos_deg(a.goals[j * a.ld + i] + a.dh.off_deg[j], s[j], c[j]);
-  chain_all<D>(s, c, a.dh, p);
+  chain_all<RtTable<D>>(s, c, RtTable<D>{a.dh}, p);
   float* o = out + i * (int64_t)(3 * D);
 #pragma unroll
   for (int j = 0; j < D; ++j)

@@ -358,7 +358,8 @@ def test_substeps_and_tolerance_parameters(m, mo):
         ls.step(rng.randint(-180, 180, size=(512, 4)))
 
 
-@pytest.mark.parametrize("kw", [dict(hw_trig=True), dict(dh_in_lds=True)])
+@pytest.mark.parametrize("kw", [dict(hw_trig=True), dict(dh_in_lds=True), dict(direct_trig=True), dict(specialize=False),
+                                dict(specialize=False, direct_trig=True), dict(specialize=False, hw_trig=True)])
 def test_kernel_variants_agree_with_oracle(m, mo, kw):
     rng = np.random.RandomState(9)
     ls = Lockstep(m, mo, 4096, 7, **kw)
