@@ -73,8 +73,8 @@ def load_traffic(workload_key):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--envs-per-gpu", type=int, default=1048576)
     ap.add_argument("--dof", type=int, default=4, choices=(4, 7))
     ap.add_argument("--targets", type=int, default=7)
@@ -85,6 +85,8 @@ def main():
     ap.add_argument("--dh-in-lds", action="store_true")
     ap.add_argument("--direct-trig", action="store_true")
     ap.add_argument("--no-specialize", action="store_true")
+    ap.add_argument("--ablate", type=int, default=0, help="diagnostic builds (results invalid): 1 skip interior "
+                    "sub-steps, 2 also skip the observation math")
     args = ap.parse_args()
 
     import torch
@@ -108,7 +110,7 @@ def main():
     radius = 51.3 if args.dof == 4 else 92.6
     eng = m.StepEngine(n_local, args.targets, dh_table=table, radius=radius, device=local_rank, env_id_base=base,
                        hw_trig=args.hw_trig, dh_in_lds=args.dh_in_lds, direct_trig=args.direct_trig,
-                       specialize=not args.no_specialize)
+                       specialize=not args.no_specialize, ablate=args.ablate)
     eng.use_torch_stream()                                      # engine launches and torch/RCCL share one ordering
     returns = eng.device_tensor(m.lib.F_TOTAL_REWARD)
     L = args.episode_len
@@ -139,6 +141,7 @@ def main():
         torch.cuda.synchronize()
 
     run_steps(args.warmup)
+    D.gather_returns(returns, n_total)          # warm the collective / allocator path once, untimed
     fence()
     kernel_ms = []
     t0 = time.perf_counter()
@@ -153,6 +156,8 @@ def main():
     # sanity on what was computed (not timed): returns are small integers, something happened
     tr = eng.total_reward()
     assert np.isfinite(tr).all() and np.all(tr == np.round(tr))
+    if args.ablate:
+        print("ABLATION BUILD: timings only, outputs are not the reference's", file=sys.stderr)
     if state["gathered"] is not None:
         assert state["gathered"].numel() == n_total
 

@@ -82,6 +82,8 @@ typedef enum mt_layout { MT_ENV_MAJOR = 0, MT_SOA = 1 } mt_layout;
 #define MT_FLAG_DH_IN_LDS 0x4u           /* stage the DH constants in LDS instead of SGPRs (measured variant;      */
                                          /* implies the runtime-table kernel)                                      */
 #define MT_FLAG_DIRECT_TRIG 0x8u         /* polynomial sincos at every interior sub-step (no recurrence)           */
+#define MT_FLAG_ABLATE_LOOP 0x100u        /* DIAGNOSTIC (results wrong): skip the interior sub-steps                */
+#define MT_FLAG_ABLATE_OBS 0x200u         /* DIAGNOSTIC (results wrong): also skip the observation arithmetic       */
 #define MT_FLAG_NO_SPECIALIZE 0x10u      /* never use a compile-time DH table even if the table matches one        */
 
 /* Constructor arguments.  Replaces Environment.__init__/Multienv.__init__

@@ -136,6 +136,8 @@ void launch_step_t(mt_handle h, bool sample) {
   switch (h->trig) {
     case 1: if (sample) MT_LAUNCH_STEP(true, 1, false); else MT_LAUNCH_STEP(false, 1, false); break;
     case 2: if (sample) MT_LAUNCH_STEP(true, 2, false); else MT_LAUNCH_STEP(false, 2, false); break;
+    case 3: if (sample) MT_LAUNCH_STEP(true, 3, false); else MT_LAUNCH_STEP(false, 3, false); break;
+    case 4: if (sample) MT_LAUNCH_STEP(true, 4, false); else MT_LAUNCH_STEP(false, 4, false); break;
     default: if (sample) MT_LAUNCH_STEP(true, 0, false); else MT_LAUNCH_STEP(false, 0, false); break;
   }
 #undef MT_LAUNCH_STEP
@@ -287,6 +289,7 @@ int mt_create(mt_handle* out, const mt_config* cfg) {
   h->D = cfg->dof;
   h->K = cfg->n_targets;
   h->trig = (cfg->flags & MT_FLAG_HW_TRIG) ? 2 : ((cfg->flags & MT_FLAG_DIRECT_TRIG) ? 1 : 0);
+  if (cfg->flags & MT_FLAG_ABLATE_LOOP) h->trig = (cfg->flags & MT_FLAG_ABLATE_OBS) ? 4 : 3;
   h->lds_table = (cfg->flags & MT_FLAG_DH_IN_LDS) != 0;
 
   auto bail = [&](int code, const std::string& msg) {

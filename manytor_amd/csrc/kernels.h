@@ -178,6 +178,7 @@ __device__ __forceinline__ bool within_box(const float (&e)[3], float x, float y
 //              dependency chains per iteration.
 //            1 polynomial sincos at every sub-step (reference-shaped, slowest)
 //            2 hardware v_sin_f32/v_cos_f32 at every interior sub-step
+//            3, 4 DIAGNOSTIC ablations for profiling (MT_FLAG_ABLATE_*): outputs wrong
 //   LDS    : stage the runtime DH constants in LDS instead of SGPRs (measured
 //            variant; BASELINE.json's north_star asks for the comparison)
 // The first and last pose are always evaluated with the polynomial sincos.
@@ -256,7 +257,9 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const StepArgs a) {
   chain_z<Tbl>(sF, cF, t, zo, ze);
   ground |= (zo < 0.f) | (ze < 0.f);
 
-  if (TRIG == 0) {
+  if (TRIG >= 3) {
+    // diagnostic builds: no interior sub-steps
+  } else if (TRIG == 0) {
     float sd[D], cd[D];
     sd[0] = 0.f;
     cd[0] = 1.f;
@@ -320,7 +323,13 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const StepArgs a) {
     const bool al = (am >> k) & 1u;
     float dist = 0.f, r = 0.f, th = 0.f;
     if (al) {
-      observe_target(el, x, y, z, dist, r, th);
+      if (TRIG == 4) {
+        dist = x + el[0];
+        r = y + el[1];
+        th = z + el[2];
+      } else {
+        observe_target(el, x, y, z, dist, r, th);
+      }
       if (within_box(e, x, y, z, a.tol)) nam &= ~(1u << k);
     } else if ((x != 0.f) | (y != 0.f) | (z != 0.f)) {  // manytor.py:148, first observation after death
       px[0] = 0.f;

@@ -63,7 +63,7 @@ class StepEngine:
 
     def __init__(self, n_envs, obj_number=10, dh_table=REF_DH_TABLE, substeps=25, pickup_tol=8.0, radius=51.3,
                  device=0, env_id_base=0, terminate_on_ground=False, hw_trig=False, dh_in_lds=False,
-                 direct_trig=False, specialize=True):
+                 direct_trig=False, specialize=True, ablate=0):
         self._lib = L.load()
         table = np.asarray(dh_table, dtype=np.float64)
         if table.ndim != 2 or table.shape[1] != 4:
@@ -85,7 +85,8 @@ class StepEngine:
         cfg.substeps = self.substeps
         cfg.flags = ((L.FLAG_TERMINATE_ON_GROUND if terminate_on_ground else 0) | (L.FLAG_HW_TRIG if hw_trig else 0)
                      | (L.FLAG_DH_IN_LDS if dh_in_lds else 0) | (L.FLAG_DIRECT_TRIG if direct_trig else 0)
-                     | (0 if specialize else L.FLAG_NO_SPECIALIZE))
+                     | (0 if specialize else L.FLAG_NO_SPECIALIZE)
+                     | (L.FLAG_ABLATE_LOOP if ablate >= 1 else 0) | (L.FLAG_ABLATE_OBS if ablate >= 2 else 0))
         cfg.pickup_tol = float(pickup_tol)
         cfg.radius = float(radius)
         if self.dof > L.MT_MAX_DOF:
