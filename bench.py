@@ -85,6 +85,7 @@ def main():
     ap.add_argument("--dh-in-lds", action="store_true")
     ap.add_argument("--direct-trig", action="store_true")
     ap.add_argument("--no-specialize", action="store_true")
+    ap.add_argument("--prefetch", type=int, default=None, choices=(0, 4, 8))
     ap.add_argument("--ablate", type=int, default=0, help="diagnostic builds (results invalid): 1 skip interior "
                     "sub-steps, 2 also skip the observation math")
     args = ap.parse_args()
@@ -110,7 +111,7 @@ def main():
     radius = 51.3 if args.dof == 4 else 92.6
     eng = m.StepEngine(n_local, args.targets, dh_table=table, radius=radius, device=local_rank, env_id_base=base,
                        hw_trig=args.hw_trig, dh_in_lds=args.dh_in_lds, direct_trig=args.direct_trig,
-                       specialize=not args.no_specialize, ablate=args.ablate)
+                       specialize=not args.no_specialize, ablate=args.ablate, prefetch=args.prefetch)
     eng.use_torch_stream()                                      # engine launches and torch/RCCL share one ordering
     returns = eng.device_tensor(m.lib.F_TOTAL_REWARD)
     L = args.episode_len

@@ -84,7 +84,9 @@ typedef enum mt_layout { MT_ENV_MAJOR = 0, MT_SOA = 1 } mt_layout;
 #define MT_FLAG_DIRECT_TRIG 0x8u         /* polynomial sincos at every interior sub-step (no recurrence)           */
 #define MT_FLAG_ABLATE_LOOP 0x100u        /* DIAGNOSTIC (results wrong): skip the interior sub-steps                */
 #define MT_FLAG_ABLATE_OBS 0x200u         /* DIAGNOSTIC (results wrong): also skip the observation arithmetic       */
-#define MT_FLAG_NO_SPECIALIZE 0x10u      /* never use a compile-time DH table even if the table matches one        */
+#define MT_FLAG_NO_SPECIALIZE 0x10u
+#define MT_FLAG_PREFETCH4 0x20u           /* request the first 4 targets before the sub-step loop (tuning)          */
+#define MT_FLAG_PREFETCH8 0x40u           /* request the first 8 targets before the sub-step loop (tuning)          */      /* never use a compile-time DH table even if the table matches one        */
 
 /* Constructor arguments.  Replaces Environment.__init__/Multienv.__init__
  * (manytor.py:130-139, :77-82) plus the literals the reference hard-codes:
@@ -141,8 +143,9 @@ MT_API int mt_sample_actions(mt_handle h, uint64_t seed, uint32_t step_idx);
 /* Environment.step() = get_observations() side effect + action() + return
  * accumulation + is_done(), manytor.py:255-260, :175-213, for all envs, one launch. */
 MT_API int mt_step(mt_handle h);
-/* The same with the action drawn in-kernel (bit-identical to mt_sample_actions
- * followed by mt_step); the drawn action is also written to the action buffer. */
+/* The same with the action drawn in-kernel (results bit-identical to mt_sample_actions followed by
+ * mt_step).  The drawn action is not stored in MT_F_ACTIONS: it is the new MT_F_GOALS (goals = action after a
+ * step, manytor.py:184), which saves 4*D bytes of traffic per env. */
 MT_API int mt_step_random(mt_handle h, uint64_t seed, uint32_t step_idx);
 /* n_steps x mt_step_random with step indices step_idx0, step_idx0+1, ... (the
  * inner loop of test_multi.py:19-21). */

@@ -35,6 +35,8 @@ FLAG_HW_TRIG = 0x2
 FLAG_DH_IN_LDS = 0x4
 FLAG_DIRECT_TRIG = 0x8
 FLAG_NO_SPECIALIZE = 0x10
+FLAG_PREFETCH4 = 0x20
+FLAG_PREFETCH8 = 0x40
 FLAG_ABLATE_LOOP = 0x100
 FLAG_ABLATE_OBS = 0x200
 

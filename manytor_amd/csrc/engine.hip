@@ -7,6 +7,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -41,6 +42,7 @@ struct mt_engine {
   bool is_reset = false;
   int trig = 0;          // 0 recurrence, 1 polynomial sincos per sub-step, 2 hardware trig per sub-step
   bool lds_table = false;
+  int kpre = 0;          // targets prefetched ahead of the sub-step loop (0, 4, 8)
   int static_kind = 0;   // 0 runtime table, 1 Ref4Table, 2 Dh7Table
   std::string err;
 };
@@ -126,7 +128,9 @@ template <class Tbl, bool LDS_OK>
 void launch_step_t(mt_handle h, bool sample) {
   const dim3 g = grid_for(h->n), b(kBlock);
 #define MT_LAUNCH_STEP(SAMPLE_, TRIG_, LDS_) \
-  hipLaunchKernelGGL((step_kernel<Tbl, SAMPLE_, TRIG_, LDS_>), g, b, 0, h->stream, h->args)
+  do { if (h->kpre == 8) hipLaunchKernelGGL((step_kernel<Tbl, SAMPLE_, TRIG_, LDS_, 8>), g, b, 0, h->stream, h->args); \
+       else if (h->kpre == 4) hipLaunchKernelGGL((step_kernel<Tbl, SAMPLE_, TRIG_, LDS_, 4>), g, b, 0, h->stream, h->args); \
+       else hipLaunchKernelGGL((step_kernel<Tbl, SAMPLE_, TRIG_, LDS_, 0>), g, b, 0, h->stream, h->args); } while (0)
   if (LDS_OK && h->lds_table) {
     if constexpr (LDS_OK) {
       if (sample) MT_LAUNCH_STEP(true, 0, true); else MT_LAUNCH_STEP(false, 0, true);
@@ -138,6 +142,7 @@ void launch_step_t(mt_handle h, bool sample) {
     case 2: if (sample) MT_LAUNCH_STEP(true, 2, false); else MT_LAUNCH_STEP(false, 2, false); break;
     case 3: if (sample) MT_LAUNCH_STEP(true, 3, false); else MT_LAUNCH_STEP(false, 3, false); break;
     case 4: if (sample) MT_LAUNCH_STEP(true, 4, false); else MT_LAUNCH_STEP(false, 4, false); break;
+    case 5: if (sample) MT_LAUNCH_STEP(true, 5, false); else MT_LAUNCH_STEP(false, 5, false); break;
     default: if (sample) MT_LAUNCH_STEP(true, 0, false); else MT_LAUNCH_STEP(false, 0, false); break;
   }
 #undef MT_LAUNCH_STEP
@@ -269,6 +274,7 @@ int mt_create(mt_handle* out, const mt_config* cfg) {
   *out = nullptr;
   MT_REQUIRE(nullptr, cfg->struct_size == (int32_t)sizeof(mt_config), "mt_config.struct_size mismatch");
   MT_REQUIRE(nullptr, cfg->n_envs >= 1, "n_envs must be >= 1");
+  MT_REQUIRE(nullptr, cfg->n_envs <= ((int64_t)1 << 30) - 256, "n_envs must be < 2^30 per handle (32-bit row offsets)");
   MT_REQUIRE(nullptr, cfg->dof >= 2 && cfg->dof <= MT_MAX_DOF, "dof must be in 2..8");
   MT_REQUIRE(nullptr, cfg->n_targets >= 1 && cfg->n_targets <= MT_MAX_TARGETS, "n_targets must be in 1..32");
   MT_REQUIRE(nullptr, cfg->substeps >= 2, "substeps must be >= 2");
@@ -286,11 +292,18 @@ int mt_create(mt_handle* out, const mt_config* cfg) {
   h->cfg = *cfg;
   h->n = cfg->n_envs;
   h->ld = (int64_t)align_up((size_t)cfg->n_envs, 256);
+  // Rows that are an exact power of two apart alias onto the same HBM channels; 4 KiB of padding per row
+  // measured +2..6 % (profiles/README.md).  MT_LD_PAD (floats) overrides it for experiments.
+  int64_t pad = (cfg->n_envs > 16384) ? 1024 : 0;
+  if (const char* env = std::getenv("MT_LD_PAD")) pad = (int64_t)align_up((size_t)std::atoll(env), 64);
+  h->ld += pad;
   h->D = cfg->dof;
   h->K = cfg->n_targets;
   h->trig = (cfg->flags & MT_FLAG_HW_TRIG) ? 2 : ((cfg->flags & MT_FLAG_DIRECT_TRIG) ? 1 : 0);
   if (cfg->flags & MT_FLAG_ABLATE_LOOP) h->trig = (cfg->flags & MT_FLAG_ABLATE_OBS) ? 4 : 3;
+  else if (cfg->flags & MT_FLAG_ABLATE_OBS) h->trig = 5;   /* OBS alone = arithmetic-only build */
   h->lds_table = (cfg->flags & MT_FLAG_DH_IN_LDS) != 0;
+  h->kpre = (cfg->flags & MT_FLAG_PREFETCH8) ? 8 : ((cfg->flags & MT_FLAG_PREFETCH4) ? 4 : 0);
 
   auto bail = [&](int code, const std::string& msg) {
     g_last_error = msg;

@@ -24,6 +24,33 @@ namespace mt {
 
 constexpr int kBlock = 256;  // 4 wavefronts
 
+// Write-only outputs of a step (observations, reward, done, end effector) are never re-read by the next
+// step.  MT_NT_STORES marks them non-temporal so they do not displace the re-read state (goals, targets,
+// alive mask, return) from L2 / Infinity Cache.
+#ifndef MT_NT_STORES
+#define MT_NT_STORES 1
+#endif
+// Row access: every SoA row is addressed as (wave-uniform row base) + (32-bit per-lane BYTE offset), which maps
+// onto the `global_load/store v, v_off, s[base:base+1]` form -- the row base stays in SGPRs and no 64-bit
+// per-lane address arithmetic is needed.  Byte offsets fit 32 bits because mt_create caps n_envs below 2^30.
+template <typename T>
+__device__ __forceinline__ T ldr(const T* row, uint32_t boff) {
+  return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(row) + boff);
+}
+template <typename T>
+__device__ __forceinline__ void str(T* row, uint32_t boff, T v) {
+  *reinterpret_cast<T*>(reinterpret_cast<char*>(row) + boff) = v;
+}
+template <typename T>
+__device__ __forceinline__ void str_stream(T* row, uint32_t boff, T v) {
+  T* p = reinterpret_cast<T*>(reinterpret_cast<char*>(row) + boff);
+#if MT_NT_STORES
+  __builtin_nontemporal_store(v, p);
+#else
+  *p = v;
+#endif
+}
+
 // Per-joint DH constants, uniform over the launch.  Passed by value in the
 // kernel arguments, so they live in SGPRs (s_load from the kernarg segment);
 // the MT_FLAG_DH_IN_LDS variant copies them to LDS first.
@@ -154,14 +181,42 @@ __device__ __forceinline__ void observe_target(const float (&el)[3], float x, fl
                                                float& th) {
   const float m0 = fabsf(el[0] - x), m1 = fabsf(el[1] - y), m2 = fabsf(el[2] - z);
   const float h2 = m0 * m0 + m1 * m1;
-  const float h = __builtin_sqrtf(h2);
-  dist = __builtin_sqrtf(h2 + m2 * m2);
+  const float h = __builtin_amdgcn_sqrtf(h2);            // v_sqrt_f32, 1 ulp: no refinement sequence
+  dist = __builtin_amdgcn_sqrtf(h2 + m2 * m2);
   r = atan2_deg_q1(m0, m1);
   th = atan2_deg_q1(h, m2);
 }
 
 __device__ __forceinline__ bool within_box(const float (&e)[3], float x, float y, float z, float tol) {
   return (fabsf(e[0] - x) <= tol) && (fabsf(e[1] - y) <= tol) && (fabsf(e[2] - z) <= tol);
+}
+
+// One target inside step(): obs2 triple (taken before the pickup, manytor.py:204), pickup test
+// (manytor.py:206), and the zeroing of a target that died earlier (manytor.py:148).
+template <bool ABLATE_OBS>
+__device__ __forceinline__ void step_target(const StepArgs& a, int64_t ld, uint32_t i, int k, uint32_t am, uint32_t& nam,
+                                            const float (&el)[3], const float (&e)[3], float x, float y, float z) {
+  const bool al = (am >> k) & 1u;
+  float dist = 0.f, r = 0.f, th = 0.f;
+  if (al) {
+    if (ABLATE_OBS) {
+      dist = x + el[0];
+      r = y + el[1];
+      th = z + el[2];
+    } else {
+      observe_target(el, x, y, z, dist, r, th);
+    }
+    if (within_box(e, x, y, z, a.tol)) nam &= ~(1u << k);
+  } else if ((x != 0.f) | (y != 0.f) | (z != 0.f)) {
+    float* row = a.points + (int64_t)(3 * k) * ld;
+    str(row, i * 4u, 0.f);
+    str(row + ld, i * 4u, 0.f);
+    str(row + 2 * ld, i * 4u, 0.f);
+  }
+  float* orow = a.obs + (int64_t)(3 * k) * ld;
+  str_stream(orow, i * 4u, dist);
+  str_stream(orow + ld, i * 4u, r);
+  str_stream(orow + 2 * ld, i * 4u, th);
 }
 
 // ---------------------------------------------------------------------------
@@ -179,6 +234,7 @@ __device__ __forceinline__ bool within_box(const float (&e)[3], float x, float y
 //            1 polynomial sincos at every sub-step (reference-shaped, slowest)
 //            2 hardware v_sin_f32/v_cos_f32 at every interior sub-step
 //            3, 4 DIAGNOSTIC ablations for profiling (MT_FLAG_ABLATE_*): outputs wrong
+//   KPRE   : number of targets whose coordinates are requested before the sub-step loop
 //   LDS    : stage the runtime DH constants in LDS instead of SGPRs (measured
 //            variant; BASELINE.json's north_star asks for the comparison)
 // The first and last pose are always evaluated with the polynomial sincos.
@@ -192,7 +248,7 @@ struct TableMaker<RtTable<D>> {
   static __device__ __forceinline__ RtTable<D> make(const DhConst& c) { return RtTable<D>{c}; }
 };
 
-template <class Tbl, bool SAMPLE, int TRIG, bool LDS>
+template <class Tbl, bool SAMPLE, int TRIG, bool LDS, int KPRE>
 __global__ __launch_bounds__(kBlock) void step_kernel(const StepArgs a) {
   constexpr int D = Tbl::D;
   __shared__ DhConst sh;
@@ -204,13 +260,27 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const StepArgs a) {
   }
   const Tbl t = TableMaker<Tbl>::make(LDS ? sh : a.dh);
 
-  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;  // 32-bit lane offset: rows are addressed as uniform base + i
   if (i >= a.n) return;
   const int64_t ld = a.ld;
 
   float g[D], act[D];
 #pragma unroll
-  for (int j = 0; j < D; ++j) g[j] = a.goals[j * ld + i];
+  for (int j = 0; j < D; ++j) g[j] = ldr(a.goals + j * ld, i * 4u);
+  // Everything else this env reads is requested now, so that HBM keeps streaming while the sub-step loop
+  // below runs on the joint angles alone: alive mask, return, and the first KPRE targets (3 rows each).
+  const uint32_t am = ldr(a.alive, i * 4u);
+  const float total_in = ldr(a.total_reward, i * 4u);
+  float pre[KPRE > 0 ? KPRE : 1][3];
+#pragma unroll
+  for (int k = 0; k < KPRE; ++k) {
+    if (k < a.K) {
+      const float* row = a.points + (int64_t)(3 * k) * ld;
+      pre[k][0] = ldr(row, i * 4u);
+      pre[k][1] = ldr(row + ld, i * 4u);
+      pre[k][2] = ldr(row + 2 * ld, i * 4u);
+    }
+  }
   if (SAMPLE) {
 #pragma unroll
     for (int b = 0; b < (D + 3) / 4; ++b) {
@@ -221,11 +291,10 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const StepArgs a) {
       for (int q = 0; q < 4; ++q)
         if (4 * b + q < D) act[4 * b + q] = action_from_word(ws[q]);
     }
-#pragma unroll
-    for (int j = 0; j < D; ++j) a.actions[j * ld + i] = act[j];
+    // not stored separately: the action taken becomes `goals` below (manytor.py:184), 4D bytes of traffic saved
   } else {
 #pragma unroll
-    for (int j = 0; j < D; ++j) act[j] = a.actions[j * ld + i];
+    for (int j = 0; j < D; ++j) act[j] = ldr(a.actions + j * ld, i * 4u);
   }
 
   // route[k] = goals + k * (action - goals) / (S-1), route[S-1] = action (np.linspace, manytor.py:182)
@@ -233,7 +302,8 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const StepArgs a) {
 #pragma unroll
   for (int j = 0; j < D; ++j) st[j] = (act[j] - g[j]) * a.inv_sm1;
 
-  bool ground = false;
+  // ground flag (manytor.py:191): any sub-step with z_elbow < 0 or z_ee < 0  <=>  min over all of them < 0
+  float zmin;
   float zo, ze;
   // k = S-1: the action itself, full chain (positions are consumed below)
   float sA[D], cA[D], p[D][3];
@@ -246,7 +316,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const StepArgs a) {
     el[q] = (D > 2) ? p[D - 2][q] : 0.f;  // joints_coordinates[-2]; row 0 is zeros (manytor.py:189)
     e[q] = p[D - 1][q];
   }
-  ground |= (el[2] < 0.f) | (e[2] < 0.f);
+  zmin = fminf(el[2], e[2]);
 
   // k = 0: the previous pose (manytor.py:182-192 evaluates it again: a pose left below ground costs -1 twice)
   float sF[D], cF[D];
@@ -255,11 +325,11 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const StepArgs a) {
 #pragma unroll
   for (int j = 1; j < D; ++j) sincos_deg(g[j] + t.off(j), sF[j], cF[j]);
   chain_z<Tbl>(sF, cF, t, zo, ze);
-  ground |= (zo < 0.f) | (ze < 0.f);
+  zmin = fminf(zmin, fminf(zo, ze));
 
-  if (TRIG >= 3) {
+  if (TRIG == 3 || TRIG == 4) {
     // diagnostic builds: no interior sub-steps
-  } else if (TRIG == 0) {
+  } else if (TRIG == 0 || TRIG == 5) {
     float sd[D], cd[D];
     sd[0] = 0.f;
     cd[0] = 1.f;
@@ -283,7 +353,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const StepArgs a) {
         cF[j] = c2;
       }
       chain_z<Tbl>(sF, cF, t, zo, ze);
-      ground |= (zo < 0.f) | (ze < 0.f);
+      zmin = fminf(zmin, fminf(zo, ze));
       if (it <= nb) {
 #pragma unroll
         for (int j = 1; j < D; ++j) {  // rotate by -delta
@@ -292,7 +362,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const StepArgs a) {
           cB[j] = c2;
         }
         chain_z<Tbl>(sB, cB, t, zo, ze);
-        ground |= (zo < 0.f) | (ze < 0.f);
+        zmin = fminf(zmin, fminf(zo, ze));
       }
     }
   } else {
@@ -310,36 +380,27 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const StepArgs a) {
           sincos_deg(pose, sF[j], cF[j]);
       }
       chain_z<Tbl>(sF, cF, t, zo, ze);
-      ground |= (zo < 0.f) | (ze < 0.f);
+      zmin = fminf(zmin, fminf(zo, ze));
     }
   }
+  const bool ground = zmin < 0.f;
 
   // obs2 (before pickup, manytor.py:204) and pickup (manytor.py:206) per target
-  const uint32_t am = a.alive[i];
   uint32_t nam = am;
-  for (int k = 0; k < a.K; ++k) {
-    float* px = a.points + (int64_t)(3 * k) * ld + i;
-    float x = px[0], y = px[ld], z = px[2 * ld];
-    const bool al = (am >> k) & 1u;
-    float dist = 0.f, r = 0.f, th = 0.f;
-    if (al) {
-      if (TRIG == 4) {
-        dist = x + el[0];
-        r = y + el[1];
-        th = z + el[2];
-      } else {
-        observe_target(el, x, y, z, dist, r, th);
-      }
+#pragma unroll
+  for (int k = 0; k < KPRE; ++k)
+    if (k < a.K) step_target<TRIG == 4>(a, ld, i, k, am, nam, el, e, pre[k][0], pre[k][1], pre[k][2]);
+  for (int k = KPRE; k < a.K; ++k) {
+    if (TRIG == 5) {  // DIAGNOSTIC: arithmetic only, no HBM traffic for targets / observations
+      float dist, r, th;
+      const float x = (float)(i & 63) + (float)k, y = 3.0f + (float)k, z = 5.0f + g[0];
+      observe_target(el, x, y, z, dist, r, th);
       if (within_box(e, x, y, z, a.tol)) nam &= ~(1u << k);
-    } else if ((x != 0.f) | (y != 0.f) | (z != 0.f)) {  // manytor.py:148, first observation after death
-      px[0] = 0.f;
-      px[ld] = 0.f;
-      px[2 * ld] = 0.f;
+      if (dist + r + th == -12345.0f) (a.obs + (int64_t)(3 * k) * ld)[i] = dist;
+      continue;
     }
-    float* po = a.obs + (int64_t)(3 * k) * ld + i;
-    po[0] = dist;
-    po[ld] = r;
-    po[2 * ld] = th;
+    const float* row = a.points + (int64_t)(3 * k) * ld;
+    step_target<TRIG == 4>(a, ld, i, k, am, nam, el, e, ldr(row, i * 4u), ldr(row + ld, i * 4u), ldr(row + 2 * ld, i * 4u));
   }
 
   const int32_t rew = ground ? -1 : ((nam != am) ? 1 : 0);  // manytor.py:205-212
@@ -347,13 +408,13 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const StepArgs a) {
   if (a.flags & MT_FLAG_TERMINATE_ON_GROUND) done |= ground;
 
 #pragma unroll
-  for (int j = 0; j < D; ++j) a.goals[j * ld + i] = act[j];
+  for (int j = 0; j < D; ++j) str(a.goals + j * ld, i * 4u, act[j]);
 #pragma unroll
-  for (int q = 0; q < 3; ++q) a.ee[q * ld + i] = e[q];
-  a.alive[i] = nam;
-  a.reward[i] = rew;
-  a.total_reward[i] += (float)rew;  // manytor.py:258
-  a.done[i] = done ? 1 : 0;
+  for (int q = 0; q < 3; ++q) str_stream(a.ee + q * ld, i * 4u, e[q]);
+  str(a.alive, i * 4u, nam);
+  str_stream(a.reward, i * 4u, rew);
+  str(a.total_reward, i * 4u, total_in + (float)rew);  // manytor.py:258
+  str_stream(a.done, i, (uint8_t)(done ? 1 : 0));
   const unsigned long long bits = __ballot(done);
   if ((threadIdx.x & 63) == 0) a.done_bits[i >> 6] = bits;
 }
@@ -381,13 +442,13 @@ __device__ __forceinline__ bool target_candidate(const u32x4& w, float radius, f
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void sample_actions_kernel(float* actions, int64_t n, int64_t ld, int D,
                                                                 int64_t env_base, uint64_t seed, uint32_t step_idx) {
-  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;  // 32-bit lane offset: rows are addressed as uniform base + i
   if (i >= n) return;
   for (int b = 0; b < (D + 3) / 4; ++b) {
     const u32x4 w = stream_block(seed, (uint64_t)(env_base + i), kTagAction, step_idx, (uint32_t)b);
     const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
     for (int q = 0; q < 4; ++q)
-      if (4 * b + q < D) actions[(int64_t)(4 * b + q) * ld + i] = action_from_word(ws[q]);
+      if (4 * b + q < D) (actions + (int64_t)(4 * b + q) * ld)[i] = action_from_word(ws[q]);
   }
 }
 
@@ -397,7 +458,7 @@ __global__ __launch_bounds__(kBlock) void sample_actions_kernel(float* actions, 
 // ---------------------------------------------------------------------------
 template <int D, bool RANDOM, bool ONLY_DONE>
 __global__ __launch_bounds__(kBlock) void reset_kernel(const StepArgs a, float radius) {
-  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;  // 32-bit lane offset: rows are addressed as uniform base + i
   if (i >= a.n) return;
   const int64_t ld = a.ld;
   const bool go = ONLY_DONE ? (a.done[i] != 0) : true;
@@ -405,12 +466,12 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(const StepArgs a, float r
     float s[D], c[D], p[D][3];
 #pragma unroll
     for (int j = 0; j < D; ++j) {
-      a.goals[j * ld + i] = 0.f;
+      (a.goals + j * ld)[i] = 0.f;
       sincos_deg(a.dh.off_deg[j], s[j], c[j]);
     }
     chain_all<RtTable<D>>(s, c, RtTable<D>{a.dh}, p);  // joints_coordinates at the zero pose, manytor.py:224-225
 #pragma unroll
-    for (int q = 0; q < 3; ++q) a.ee[q * ld + i] = p[D - 1][q];
+    for (int q = 0; q < 3; ++q) (a.ee + q * ld)[i] = p[D - 1][q];
     a.total_reward[i] = 0.f;
     a.reward[i] = 0;
     a.done[i] = 0;
@@ -424,18 +485,18 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(const StepArgs a, float r
         const u32x4 w = stream_block(seed, (uint64_t)(a.env_base + i), kTagTarget, a.major, draw);
         float x, y, z;
         if (target_candidate(w, radius, x, y, z)) {
-          float* px = a.points + (int64_t)(3 * cnt) * ld + i;
-          px[0] = x;
-          px[ld] = y;
-          px[2 * ld] = z;
+          float* row = a.points + (int64_t)(3 * cnt) * ld;
+          row[i] = x;
+          (row + ld)[i] = y;
+          (row + 2 * ld)[i] = z;
           ++cnt;
         }
       }
       for (; cnt < a.K; ++cnt) {  // unreachable in practice (p < 1e-1000); keeps the loop bounded
-        float* px = a.points + (int64_t)(3 * cnt) * ld + i;
-        px[0] = 0.f;
-        px[ld] = 0.f;
-        px[2 * ld] = 0.5f * radius;
+        float* row = a.points + (int64_t)(3 * cnt) * ld;
+        row[i] = 0.f;
+        (row + ld)[i] = 0.f;
+        (row + 2 * ld)[i] = 0.5f * radius;
       }
     }
   }
@@ -450,32 +511,32 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(const StepArgs a, float r
 // ---------------------------------------------------------------------------
 template <int D>
 __global__ __launch_bounds__(kBlock) void observe_kernel(const StepArgs a) {
-  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;  // 32-bit lane offset: rows are addressed as uniform base + i
   if (i >= a.n) return;
   const int64_t ld = a.ld;
   float s[D], c[D], p[D][3];
 #pragma unroll
-  for (int j = 0; j < D; ++j) sincos_deg(a.goals[j * ld + i] + a.dh.off_deg[j], s[j], c[j]);
+  for (int j = 0; j < D; ++j) sincos_deg((a.goals + j * ld)[i] + a.dh.off_deg[j], s[j], c[j]);
   chain_all<RtTable<D>>(s, c, RtTable<D>{a.dh}, p);
   float el[3];
 #pragma unroll
   for (int q = 0; q < 3; ++q) el[q] = (D > 2) ? p[D - 2][q] : 0.f;
   const uint32_t am = a.alive[i];
   for (int k = 0; k < a.K; ++k) {
-    float* px = a.points + (int64_t)(3 * k) * ld + i;
-    const float x = px[0], y = px[ld], z = px[2 * ld];
+    float* row = a.points + (int64_t)(3 * k) * ld;
+    const float x = row[i], y = (row + ld)[i], z = (row + 2 * ld)[i];
     float dist = 0.f, r = 0.f, th = 0.f;
     if ((am >> k) & 1u) {
       observe_target(el, x, y, z, dist, r, th);
     } else if ((x != 0.f) | (y != 0.f) | (z != 0.f)) {
-      px[0] = 0.f;
-      px[ld] = 0.f;
-      px[2 * ld] = 0.f;
+      row[i] = 0.f;
+      (row + ld)[i] = 0.f;
+      (row + 2 * ld)[i] = 0.f;
     }
-    float* po = a.obs + (int64_t)(3 * k) * ld + i;
-    po[0] = dist;
-    po[ld] = r;
-    po[2 * ld] = th;
+    float* orow = a.obs + (int64_t)(3 * k) * ld;
+    orow[i] = dist;
+    (orow + ld)[i] = r;
+    (orow + 2 * ld)[i] = th;
   }
 }
 
@@ -484,12 +545,12 @@ __global__ __launch_bounds__(kBlock) void observe_kernel(const StepArgs a) {
 // ---------------------------------------------------------------------------
 template <int D>
 __global__ __launch_bounds__(kBlock) void check_done_kernel(const StepArgs a) {
-  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;  // 32-bit lane offset: rows are addressed as uniform base + i
   if (i >= a.n) return;
   const int64_t ld = a.ld;
   float s[D], c[D], p[D][3];
 #pragma unroll
-  for (int j = 0; j < D; ++j) sincos_deg(a.goals[j * ld + i] + a.dh.off_deg[j], s[j], c[j]);
+  for (int j = 0; j < D; ++j) sincos_deg((a.goals + j * ld)[i] + a.dh.off_deg[j], s[j], c[j]);
   chain_all<RtTable<D>>(s, c, RtTable<D>{a.dh}, p);
   float e[3];
 #pragma unroll
@@ -497,8 +558,8 @@ __global__ __launch_bounds__(kBlock) void check_done_kernel(const StepArgs a) {
   uint32_t am = a.alive[i];
   for (int k = 0; k < a.K; ++k) {
     if (!((am >> k) & 1u)) continue;
-    const float* px = a.points + (int64_t)(3 * k) * ld + i;
-    if (within_box(e, px[0], px[ld], px[2 * ld], a.tol)) am &= ~(1u << k);
+    const float* row = a.points + (int64_t)(3 * k) * ld;
+    if (within_box(e, row[i], (row + ld)[i], (row + 2 * ld)[i], a.tol)) am &= ~(1u << k);
   }
   a.alive[i] = am;
   const bool done = (am == 0u);
@@ -511,13 +572,14 @@ __global__ __launch_bounds__(kBlock) void check_done_kernel(const StepArgs a) {
 // frame after j+1 joints (manytor.py:188-189).
 template <int D>
 __global__ __launch_bounds__(kBlock) void joints_kernel(const StepArgs a, float* out) {
-  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;  // 32-bit lane offset: rows are addressed as uniform base + i
   if (i >= a.n) return;
+  const int64_t ld = a.ld;
   float s[D], c[D], p[D][3];
 #pragma unroll
-  for (int j = 0; j < D; ++j) sincos_deg(a.goals[j * a.ld + i] + a.dh.off_deg[j], s[j], c[j]);
+  for (int j = 0; j < D; ++j) sincos_deg((a.goals + j * ld)[i] + a.dh.off_deg[j], s[j], c[j]);
   chain_all<RtTable<D>>(s, c, RtTable<D>{a.dh}, p);
-  float* o = out + i * (int64_t)(3 * D);
+  float* o = out + (int64_t)i * (3 * D);
 #pragma unroll
   for (int j = 0; j < D; ++j)
 #pragma unroll
@@ -530,37 +592,37 @@ __global__ __launch_bounds__(kBlock) void joints_kernel(const StepArgs a, float*
 // ---------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(kBlock) void soa_to_env_major(const T* src, int64_t ld, int rows, int64_t n, T* dst) {
-  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;  // 32-bit lane offset: rows are addressed as uniform base + i
   if (i >= n) return;
-  for (int r = 0; r < rows; ++r) dst[i * rows + r] = src[(int64_t)r * ld + i];
+  for (int r = 0; r < rows; ++r) dst[(int64_t)i * rows + r] = (src + (int64_t)r * ld)[i];
 }
 
 template <typename S>
 __global__ __launch_bounds__(kBlock) void env_major_to_soa(const S* src, int rows, int64_t n, float* dst, int64_t ld) {
-  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;  // 32-bit lane offset: rows are addressed as uniform base + i
   if (i >= n) return;
-  for (int r = 0; r < rows; ++r) dst[(int64_t)r * ld + i] = (float)src[i * rows + r];
+  for (int r = 0; r < rows; ++r) (dst + (int64_t)r * ld)[i] = (float)src[(int64_t)i * rows + r];
 }
 
 template <typename S>
 __global__ __launch_bounds__(kBlock) void soa_to_soa_f32(const S* src, int rows, int64_t n, int64_t ld, float* dst) {
-  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;  // 32-bit lane offset: rows are addressed as uniform base + i
   if (i >= n) return;
-  for (int r = 0; r < rows; ++r) dst[(int64_t)r * ld + i] = (float)src[(int64_t)r * ld + i];
+  for (int r = 0; r < rows; ++r) (dst + (int64_t)r * ld)[i] = (float)(src + (int64_t)r * ld)[i];
 }
 
 __global__ __launch_bounds__(kBlock) void alive_unpack(const uint32_t* mask, int K, int64_t n, uint8_t* dst) {
-  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;  // 32-bit lane offset: rows are addressed as uniform base + i
   if (i >= n) return;
   const uint32_t m = mask[i];
-  for (int k = 0; k < K; ++k) dst[i * K + k] = (m >> k) & 1u;
+  for (int k = 0; k < K; ++k) dst[(int64_t)i * K + k] = (m >> k) & 1u;
 }
 
 __global__ __launch_bounds__(kBlock) void alive_pack(const uint8_t* src, int K, int64_t n, uint32_t* mask) {
-  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;  // 32-bit lane offset: rows are addressed as uniform base + i
   if (i >= n) return;
   uint32_t m = 0;
-  for (int k = 0; k < K; ++k) m |= (src[i * K + k] ? 1u : 0u) << k;
+  for (int k = 0; k < K; ++k) m |= (src[(int64_t)i * K + k] ? 1u : 0u) << k;
   mask[i] = m;
 }
 
@@ -576,11 +638,11 @@ struct FkArgs {
 };
 
 __global__ __launch_bounds__(kBlock) void fk_kernel(const FkArgs a) {
-  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;  // 32-bit lane offset: rows are addressed as uniform base + i
   if (i >= a.n) return;
   float X[3] = {1.f, 0.f, 0.f}, Y[3] = {0.f, 1.f, 0.f}, Z[3] = {0.f, 0.f, 1.f}, o[3] = {0.f, 0.f, 0.f};
   for (int j = 0; j < a.mode; ++j) {
-    float ang = a.angles[i * a.dof + j];
+    float ang = a.angles[(int64_t)i * a.dof + j];
     if (a.radians) ang *= 57.29577951308232f;
     float s, c;
     sincos_deg(ang + a.dh.off_deg[j], s, c);
@@ -593,7 +655,7 @@ __global__ __launch_bounds__(kBlock) void fk_kernel(const FkArgs a) {
       Z[q] = Z[q] * a.dh.ca[j] - tt * a.dh.sa[j];
     }
   }
-  float* m = a.out + i * 16;
+  float* m = a.out + (int64_t)i * 16;
   for (int q = 0; q < 3; ++q) {
     m[4 * q + 0] = X[q];
     m[4 * q + 1] = Y[q];
@@ -607,13 +669,13 @@ __global__ __launch_bounds__(kBlock) void fk_kernel(const FkArgs a) {
 }
 
 __global__ __launch_bounds__(kBlock) void r_theta_kernel(const float* v1, const float* v2, int64_t n, float* out) {
-  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;  // 32-bit lane offset: rows are addressed as uniform base + i
   if (i >= n) return;
-  const float d0 = fabsf(v1[3 * i] - v2[3 * i]), d1 = fabsf(v1[3 * i + 1] - v2[3 * i + 1]),
-              d2 = fabsf(v1[3 * i + 2] - v2[3 * i + 2]);
-  const float h = __builtin_sqrtf(d0 * d0 + d1 * d1);
-  out[2 * i] = atan2_deg_q1(d0, d1);
-  out[2 * i + 1] = atan2_deg_q1(h, d2);
+  const int64_t b3 = 3 * (int64_t)i;
+  const float d0 = fabsf(v1[b3] - v2[b3]), d1 = fabsf(v1[b3 + 1] - v2[b3 + 1]), d2 = fabsf(v1[b3 + 2] - v2[b3 + 2]);
+  const float h = __builtin_amdgcn_sqrtf(d0 * d0 + d1 * d1);
+  out[2 * (int64_t)i] = atan2_deg_q1(d0, d1);
+  out[2 * (int64_t)i + 1] = atan2_deg_q1(h, d2);
 }
 
 }  // namespace mt

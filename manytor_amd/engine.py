@@ -63,7 +63,7 @@ class StepEngine:
 
     def __init__(self, n_envs, obj_number=10, dh_table=REF_DH_TABLE, substeps=25, pickup_tol=8.0, radius=51.3,
                  device=0, env_id_base=0, terminate_on_ground=False, hw_trig=False, dh_in_lds=False,
-                 direct_trig=False, specialize=True, ablate=0):
+                 direct_trig=False, specialize=True, ablate=0, prefetch=None):
         self._lib = L.load()
         table = np.asarray(dh_table, dtype=np.float64)
         if table.ndim != 2 or table.shape[1] != 4:
@@ -86,7 +86,8 @@ class StepEngine:
         cfg.flags = ((L.FLAG_TERMINATE_ON_GROUND if terminate_on_ground else 0) | (L.FLAG_HW_TRIG if hw_trig else 0)
                      | (L.FLAG_DH_IN_LDS if dh_in_lds else 0) | (L.FLAG_DIRECT_TRIG if direct_trig else 0)
                      | (0 if specialize else L.FLAG_NO_SPECIALIZE)
-                     | (L.FLAG_ABLATE_LOOP if ablate >= 1 else 0) | (L.FLAG_ABLATE_OBS if ablate >= 2 else 0))
+                     | {None: 0, 0: 0, 4: L.FLAG_PREFETCH4, 8: L.FLAG_PREFETCH8}[prefetch]
+                     | (L.FLAG_ABLATE_LOOP if ablate in (1, 2) else 0) | (L.FLAG_ABLATE_OBS if ablate in (2, 3) else 0))
         cfg.pickup_tol = float(pickup_tol)
         cfg.radius = float(radius)
         if self.dof > L.MT_MAX_DOF:

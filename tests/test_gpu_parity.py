@@ -402,7 +402,7 @@ def test_step_random_equals_sample_then_step(m):
         a.sample_actions(9, t)
         a.step()
         b.step_random(9, t)
-    for f in (m.lib.F_ACTIONS, m.lib.F_GOALS, m.lib.F_OBS, m.lib.F_REWARD, m.lib.F_DONE, m.lib.F_ALIVE, m.lib.F_EE,
+    for f in (m.lib.F_GOALS, m.lib.F_OBS, m.lib.F_REWARD, m.lib.F_DONE, m.lib.F_ALIVE, m.lib.F_EE,
               m.lib.F_TOTAL_REWARD, m.lib.F_POINTS, m.lib.F_DONE_BITS):
         np.testing.assert_array_equal(a.get(f), b.get(f))
     c = m.StepEngine(n, k)
@@ -438,6 +438,7 @@ def test_full_size_properties(m, mo, n, table_name):
     table = m.REF_DH_TABLE if table_name == "ref" else m.DH7_TABLE
     radius = 51.3 if table_name == "ref" else 92.6
     dof, k = len(table), 7
+    from oracle import philox_ref as px
     eng = m.StepEngine(n, k, dh_table=table, radius=radius)
     eng.reset_random(0x5EED, 0)
     p0 = eng.points()
@@ -449,13 +450,13 @@ def test_full_size_properties(m, mo, n, table_name):
     ever_guarded = np.zeros(len(sample), dtype=bool)
     for t in range(4):
         eng.step_random(0x5EED, t)
-        a = eng.actions()
+        a = eng.goals()               # the action drawn in-kernel is the new goals (manytor.py:184)
         assert a.min() >= -180 and a.max() <= 179 and np.all(a == np.round(a))
         rew, done, alive, obs = eng.reward(), eng.done(), eng.alives(), eng.obs()
         ret += rew
         assert set(np.unique(rew)) <= {-1, 0, 1}
         np.testing.assert_array_equal(done, ~alive.any(axis=1))
-        np.testing.assert_array_equal(eng.goals(), a)                              # goals = action (manytor.py:184)
+        np.testing.assert_array_equal(a, px.sample_actions(0x5EED, np.arange(n, dtype=np.uint64), t, dof))
         o = obs.reshape(n, k, 3)
         assert np.isfinite(o).all() and (o >= 0).all() and (o[..., 1:] <= 90.0 + 1e-3).all()
         pre_alive = ora.alives.copy()
