@@ -81,6 +81,10 @@ def main():
     ap.add_argument("--episode-len", type=int, default=50)       # test_multi.py:8
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x5EED)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
+                    help="collective backend for N > 1: nccl = RCCL over xGMI (default); gloo = CPU rehearsal")
+    ap.add_argument("--single-device", action="store_true",
+                    help="rehearsal only: put every rank on GPU 0 (use with --backend gloo on a 1-GPU box)")
     ap.add_argument("--hw-trig", action="store_true")
     ap.add_argument("--dh-in-lds", action="store_true")
     ap.add_argument("--direct-trig", action="store_true")
@@ -101,15 +105,21 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available() or m.device_count() < 1:
         raise SystemExit("bench.py needs a GPU: the step path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    D.init_process_group("nccl" if world > 1 else None)
+    dev = 0 if args.single_device else local_rank
+    torch.cuda.set_device(dev)
+    if world > 1:
+        if args.backend == "nccl":
+            D.init_process_group("nccl")
+        else:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
 
     n_local = args.envs_per_gpu
     n_total = n_local * world                                   # weak scaling: per-GPU work fixed
     base = rank * n_local
     table = m.REF_DH_TABLE if args.dof == 4 else m.DH7_TABLE
     radius = 51.3 if args.dof == 4 else 92.6
-    eng = m.StepEngine(n_local, args.targets, dh_table=table, radius=radius, device=local_rank, env_id_base=base,
+    eng = m.StepEngine(n_local, args.targets, dh_table=table, radius=radius, device=dev, env_id_base=base,
                        hw_trig=args.hw_trig, dh_in_lds=args.dh_in_lds, direct_trig=args.direct_trig,
                        specialize=not args.no_specialize, ablate=args.ablate, prefetch=args.prefetch)
     eng.use_torch_stream()                                      # engine launches and torch/RCCL share one ordering
@@ -132,7 +142,8 @@ def main():
             state["step"] += seg
             done += seg
             if state["step"] % L == 0:
-                state["gathered"] = D.gather_returns(returns, n_total)      # RCCL all-gather (identity at N=1)
+                src = returns if args.backend == "nccl" or world == 1 else returns.cpu()
+                state["gathered"] = D.gather_returns(src, n_total)          # RCCL all-gather (identity at N=1)
                 state["episode"] += 1
                 eng.reset_random(args.seed, state["episode"])
 
@@ -142,7 +153,7 @@ def main():
         torch.cuda.synchronize()
 
     run_steps(args.warmup)
-    D.gather_returns(returns, n_total)          # warm the collective / allocator path once, untimed
+    D.gather_returns(returns if args.backend == "nccl" or world == 1 else returns.cpu(), n_total)   # warm-up, untimed
     fence()
     kernel_ms = []
     t0 = time.perf_counter()
@@ -150,7 +161,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -181,7 +192,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload, "envs_per_gpu": n_local, "envs_total": n_total, "dof": args.dof,
                        "targets": args.targets, "substeps": 25, "episode_len": L,
-                       "collective": "RCCL all-gather of returns per episode" if world > 1 else "none (1 GPU)",
+                       "collective": (f"{'RCCL' if args.backend == 'nccl' else 'gloo (rehearsal)'} all-gather of returns per episode"
+                                      if world > 1 else "none (1 GPU)"),
                        "kernel_variant": variant},
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

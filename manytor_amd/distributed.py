@@ -63,11 +63,10 @@ def gather_returns(local_returns, n_total: int, group=None):
     if local_returns.numel() != counts[rank]:
         raise ValueError(f"rank {rank} holds {local_returns.numel()} returns, expected {counts[rank]}")
     cmax = max(counts)
-    send = local_returns.contiguous()
-    if send.numel() != cmax:
-        pad = torch.zeros(cmax, dtype=send.dtype, device=send.device)
-        pad[: send.numel()] = send
-        send = pad
+    # stage into torch-owned memory: the source may be a zero-copy view of the engine's arena, which the
+    # collective library has never seen (4 B per env, negligible next to an episode)
+    send = torch.zeros(cmax, dtype=local_returns.dtype, device=local_returns.device)
+    send[: local_returns.numel()] = local_returns
     out = torch.empty(world * cmax, dtype=send.dtype, device=send.device)
     dist.all_gather_into_tensor(out, send, group=group)
     if all(c == cmax for c in counts):
