@@ -89,7 +89,9 @@ def main():
     ap.add_argument("--dh-in-lds", action="store_true")
     ap.add_argument("--direct-trig", action="store_true")
     ap.add_argument("--no-specialize", action="store_true")
-    ap.add_argument("--prefetch", type=int, default=None, choices=(0, 4, 8))
+    ap.add_argument("--fused", action="store_true",
+                    help="secondary mode: each episode segment is ONE mt_rollout_fused launch (state kept on chip "
+                         "between steps); the roofline object then describes that kernel")
     ap.add_argument("--ablate", type=int, default=0, help="diagnostic builds (results invalid): 1 skip interior "
                     "sub-steps, 2 also skip the observation math")
     args = ap.parse_args()
@@ -121,7 +123,7 @@ def main():
     radius = 51.3 if args.dof == 4 else 92.6
     eng = m.StepEngine(n_local, args.targets, dh_table=table, radius=radius, device=dev, env_id_base=base,
                        hw_trig=args.hw_trig, dh_in_lds=args.dh_in_lds, direct_trig=args.direct_trig,
-                       specialize=not args.no_specialize, ablate=args.ablate, prefetch=args.prefetch)
+                       specialize=not args.no_specialize, ablate=args.ablate)
     eng.use_torch_stream()                                      # engine launches and torch/RCCL share one ordering
     returns = eng.device_tensor(m.lib.F_TOTAL_REWARD)
     L = args.episode_len
@@ -136,7 +138,10 @@ def main():
             seg = min(count - done, L - state["step"] % L)
             if kernel_ms is not None:
                 eng.timer_start()
-            eng.rollout(seg, args.seed, state["step"])
+            if args.fused:
+                eng.rollout_fused(seg, args.seed, state["step"])
+            else:
+                eng.rollout(seg, args.seed, state["step"])
             if kernel_ms is not None:
                 kernel_ms.append((eng.timer_stop(), seg))
             state["step"] += seg
@@ -175,7 +180,7 @@ def main():
 
     if rank == 0:
         bpe = algorithmic_bytes_per_env_step(args.dof, args.targets)
-        launches = sum(s for _, s in kernel_ms)
+        launches = sum(s for _, s in kernel_ms)       # env-steps per env; = launches of step_kernel unless --fused
         avg_kernel_s = sum(ms for ms, _ in kernel_ms) / launches / 1e3
         achieved = bpe * n_local / avg_kernel_s / 1e9
         trig = 2 if args.hw_trig else (1 if args.direct_trig else 0)
@@ -199,7 +204,8 @@ def main():
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": load_traffic(f"d{args.dof}_k{args.targets}_n{n_local}"),
-                "kernel": f"step_kernel<{table_name}, sample=true, trig={trig}, lds={str(args.dh_in_lds).lower()}>",
+                "kernel": (f"rollout_kernel<{table_name}> ({L} steps per launch; us per step quoted)" if args.fused else
+                           f"step_kernel<{table_name}, sample=true, trig={trig}, lds={str(args.dh_in_lds).lower()}>"),
                 "bytes_per_env_step": bpe, "avg_kernel_us": avg_kernel_s * 1e6,
             },
         }

@@ -69,7 +69,9 @@ typedef enum mt_field {
   MT_F_EE = 8,            /* f32  (N, 3)                rows: 3            end effector = joints_coordinates[-1] */
   MT_F_TOTAL_REWARD = 9,  /* f32  (N,)                                      manytor.py:138 `total_reward`     */
   MT_F_JOINTS = 10,       /* f32  (N, D, 3) computed on demand from goals (manytor.py:188-189); mt_get only  */
-  MT_F_COUNT = 11
+  MT_F_EPISODES = 11,     /* u32  (N,)   episode index of each env: set by a reset, +1 per auto re-arm          */
+  MT_F_LAST_RETURN = 12,  /* f32  (N,)   total_reward the env had when it was last reset / re-armed             */
+  MT_F_COUNT = 13
 } mt_field;
 
 typedef enum mt_dtype { MT_F32 = 0, MT_F64 = 1, MT_I32 = 2, MT_I64 = 3, MT_U8 = 4, MT_U32 = 5, MT_U64 = 6 } mt_dtype;
@@ -85,8 +87,6 @@ typedef enum mt_layout { MT_ENV_MAJOR = 0, MT_SOA = 1 } mt_layout;
 #define MT_FLAG_ABLATE_LOOP 0x100u        /* DIAGNOSTIC (results wrong): skip the interior sub-steps                */
 #define MT_FLAG_ABLATE_OBS 0x200u         /* DIAGNOSTIC (results wrong): also skip the observation arithmetic       */
 #define MT_FLAG_NO_SPECIALIZE 0x10u
-#define MT_FLAG_PREFETCH4 0x20u           /* request the first 4 targets before the sub-step loop (tuning)          */
-#define MT_FLAG_PREFETCH8 0x40u           /* request the first 8 targets before the sub-step loop (tuning)          */      /* never use a compile-time DH table even if the table matches one        */
 
 /* Constructor arguments.  Replaces Environment.__init__/Multienv.__init__
  * (manytor.py:130-139, :77-82) plus the literals the reference hard-codes:
@@ -128,10 +128,10 @@ MT_API int mt_sync(mt_handle h);
  * seed / global env id / episode), same law as manytor.py:229-239. */
 MT_API int mt_reset(mt_handle h, const float* points, int layout, int is_device);
 MT_API int mt_reset_random(mt_handle h, uint64_t seed, uint32_t episode);
-/* Re-arm only the envs whose done byte is set (new targets from the device RNG,
- * zero pose, zero return).  Not in the reference (the caller resets everything,
- * test_multi.py:34); SURVEY.md 8(f) rank 1. */
-MT_API int mt_reset_done(mt_handle h, uint64_t seed, uint32_t episode);
+/* Re-arm only the envs whose done byte is set: their return goes to MT_F_LAST_RETURN, their episode index
+ * (MT_F_EPISODES) advances by one and keys the new targets (device RNG), pose and return are zeroed.  Not in
+ * the reference (the caller resets everything, test_multi.py:34); SURVEY.md 8(f) rank 1. */
+MT_API int mt_reset_done(mt_handle h, uint64_t seed);
 
 /* Stage the action of the next mt_step: (N, D) env-major or (D, ld) SoA, degrees,
  * any of f32/f64/i32/i64 (Environment.action_sample returns np.int64, manytor.py:216). */
@@ -150,6 +150,11 @@ MT_API int mt_step_random(mt_handle h, uint64_t seed, uint32_t step_idx);
 /* n_steps x mt_step_random with step indices step_idx0, step_idx0+1, ... (the
  * inner loop of test_multi.py:19-21). */
 MT_API int mt_rollout(mt_handle h, int n_steps, uint64_t seed, uint32_t step_idx0);
+/* The same n_steps steps in ONE launch: joint angles, alive mask and return stay in registers and the targets
+ * in LDS between steps, so a step only writes its outputs (obs, reward, done, end effector; MT_F_* hold the last
+ * step's).  auto_reset != 0 re-arms an env in the step it finishes, exactly like mt_reset_done after every step.
+ * State after the call is bit-identical to the launch-per-step sequence. */
+MT_API int mt_rollout_fused(mt_handle h, int n_steps, uint64_t seed, uint32_t step_idx0, int auto_reset);
 
 /* Environment.get_observations(), manytor.py:141-153, at the current pose (also
  * zeroes the coordinates of dead targets, :148).  Result in MT_F_OBS. */

@@ -24,7 +24,8 @@ MT_ERR_STATE = -5
 MT_ERR_UNSUPPORTED = -6
 
 # mt_field
-F_ACTIONS, F_GOALS, F_POINTS, F_ALIVE, F_OBS, F_REWARD, F_DONE, F_DONE_BITS, F_EE, F_TOTAL_REWARD, F_JOINTS = range(11)
+(F_ACTIONS, F_GOALS, F_POINTS, F_ALIVE, F_OBS, F_REWARD, F_DONE, F_DONE_BITS, F_EE, F_TOTAL_REWARD, F_JOINTS,
+ F_EPISODES, F_LAST_RETURN) = range(13)
 # mt_dtype
 DT_F32, DT_F64, DT_I32, DT_I64, DT_U8, DT_U32, DT_U64 = range(7)
 # mt_layout
@@ -35,8 +36,6 @@ FLAG_HW_TRIG = 0x2
 FLAG_DH_IN_LDS = 0x4
 FLAG_DIRECT_TRIG = 0x8
 FLAG_NO_SPECIALIZE = 0x10
-FLAG_PREFETCH4 = 0x20
-FLAG_PREFETCH8 = 0x40
 FLAG_ABLATE_LOOP = 0x100
 FLAG_ABLATE_OBS = 0x200
 
@@ -79,12 +78,13 @@ PROTOTYPES = {
     "mt_sync": (C.c_int, [_HANDLE]),
     "mt_reset": (C.c_int, [_HANDLE, C.c_void_p, C.c_int, C.c_int]),
     "mt_reset_random": (C.c_int, [_HANDLE, C.c_uint64, C.c_uint32]),
-    "mt_reset_done": (C.c_int, [_HANDLE, C.c_uint64, C.c_uint32]),
+    "mt_reset_done": (C.c_int, [_HANDLE, C.c_uint64]),
     "mt_set_actions": (C.c_int, [_HANDLE, C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "mt_sample_actions": (C.c_int, [_HANDLE, C.c_uint64, C.c_uint32]),
     "mt_step": (C.c_int, [_HANDLE]),
     "mt_step_random": (C.c_int, [_HANDLE, C.c_uint64, C.c_uint32]),
     "mt_rollout": (C.c_int, [_HANDLE, C.c_int, C.c_uint64, C.c_uint32]),
+    "mt_rollout_fused": (C.c_int, [_HANDLE, C.c_int, C.c_uint64, C.c_uint32, C.c_int]),
     "mt_observe": (C.c_int, [_HANDLE]),
     "mt_check_done": (C.c_int, [_HANDLE]),
     "mt_get": (C.c_int, [_HANDLE, C.c_int, C.c_void_p, C.c_int64, C.c_int]),

@@ -42,7 +42,6 @@ struct mt_engine {
   bool is_reset = false;
   int trig = 0;          // 0 recurrence, 1 polynomial sincos per sub-step, 2 hardware trig per sub-step
   bool lds_table = false;
-  int kpre = 0;          // targets prefetched ahead of the sub-step loop (0, 4, 8)
   int static_kind = 0;   // 0 runtime table, 1 Ref4Table, 2 Dh7Table
   std::string err;
 };
@@ -128,9 +127,7 @@ template <class Tbl, bool LDS_OK>
 void launch_step_t(mt_handle h, bool sample) {
   const dim3 g = grid_for(h->n), b(kBlock);
 #define MT_LAUNCH_STEP(SAMPLE_, TRIG_, LDS_) \
-  do { if (h->kpre == 8) hipLaunchKernelGGL((step_kernel<Tbl, SAMPLE_, TRIG_, LDS_, 8>), g, b, 0, h->stream, h->args); \
-       else if (h->kpre == 4) hipLaunchKernelGGL((step_kernel<Tbl, SAMPLE_, TRIG_, LDS_, 4>), g, b, 0, h->stream, h->args); \
-       else hipLaunchKernelGGL((step_kernel<Tbl, SAMPLE_, TRIG_, LDS_, 0>), g, b, 0, h->stream, h->args); } while (0)
+  hipLaunchKernelGGL((step_kernel<Tbl, SAMPLE_, TRIG_, LDS_>), g, b, 0, h->stream, h->args)
   if (LDS_OK && h->lds_table) {
     if constexpr (LDS_OK) {
       if (sample) MT_LAUNCH_STEP(true, 0, true); else MT_LAUNCH_STEP(false, 0, true);
@@ -204,6 +201,12 @@ void launch_joints_d(mt_handle h, float* out) {
   hipLaunchKernelGGL((joints_kernel<D>), grid_for(h->n), dim3(kBlock), 0, h->stream, h->args, out);
 }
 
+template <class Tbl>
+void launch_rollout_t(mt_handle h, const RolloutArgs& r) {
+  const size_t lds = (size_t)3 * h->K * kBlock * sizeof(float);
+  hipLaunchKernelGGL((rollout_kernel<Tbl>), grid_for(h->n), dim3(kBlock), lds, h->stream, h->args, r);
+}
+
 int check_launch(mt_handle h, const char* what) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(h, MT_ERR_HIP, std::string(what) + " launch: " + hipGetErrorString(e));
@@ -230,6 +233,8 @@ int field_info(mt_handle h, int field, FieldInfo* fi) {
     case MT_F_DONE_BITS: *fi = {a.done_bits, 1, MT_U64, 8}; return MT_OK;
     case MT_F_EE: *fi = {a.ee, 3, MT_F32, 4}; return MT_OK;
     case MT_F_TOTAL_REWARD: *fi = {a.total_reward, 1, MT_F32, 4}; return MT_OK;
+    case MT_F_EPISODES: *fi = {a.episodes, 1, MT_U32, 4}; return MT_OK;
+    case MT_F_LAST_RETURN: *fi = {a.last_return, 1, MT_F32, 4}; return MT_OK;
     default: return fail(h, MT_ERR_INVALID_ARG, "unknown or non-resident field");
   }
 }
@@ -303,7 +308,6 @@ int mt_create(mt_handle* out, const mt_config* cfg) {
   if (cfg->flags & MT_FLAG_ABLATE_LOOP) h->trig = (cfg->flags & MT_FLAG_ABLATE_OBS) ? 4 : 3;
   else if (cfg->flags & MT_FLAG_ABLATE_OBS) h->trig = 5;   /* OBS alone = arithmetic-only build */
   h->lds_table = (cfg->flags & MT_FLAG_DH_IN_LDS) != 0;
-  h->kpre = (cfg->flags & MT_FLAG_PREFETCH8) ? 8 : ((cfg->flags & MT_FLAG_PREFETCH4) ? 4 : 0);
 
   auto bail = [&](int code, const std::string& msg) {
     g_last_error = msg;
@@ -336,7 +340,8 @@ int mt_create(mt_handle* out, const mt_config* cfg) {
   };
   const size_t o_act = take(D * ld * 4), o_goal = take(D * ld * 4), o_pts = take(3 * K * ld * 4),
                o_obs = take(3 * K * ld * 4), o_alive = take(ld * 4), o_tot = take(ld * 4), o_rew = take(ld * 4),
-               o_done = take(ld), o_bits = take(ld / 64 * 8), o_ee = take(3 * ld * 4);
+               o_done = take(ld), o_bits = take(ld / 64 * 8), o_ee = take(3 * ld * 4), o_epi = take(ld * 4),
+               o_last = take(ld * 4);
   h->arena_bytes = off;
   if (hipMalloc(&h->arena, h->arena_bytes) != hipSuccess) {
     (void)hipGetLastError();
@@ -355,6 +360,8 @@ int mt_create(mt_handle* out, const mt_config* cfg) {
   a.done = (uint8_t*)(base + o_done);
   a.done_bits = (unsigned long long*)(base + o_bits);
   a.ee = (float*)(base + o_ee);
+  a.episodes = (uint32_t*)(base + o_epi);
+  a.last_return = (float*)(base + o_last);
   a.n = h->n;
   a.ld = h->ld;
   a.env_base = cfg->env_id_base;
@@ -444,10 +451,10 @@ static int reset_random_impl(mt_handle h, uint64_t seed, uint32_t episode, int m
 
 int mt_reset_random(mt_handle h, uint64_t seed, uint32_t episode) { return reset_random_impl(h, seed, episode, 1); }
 
-int mt_reset_done(mt_handle h, uint64_t seed, uint32_t episode) {
+int mt_reset_done(mt_handle h, uint64_t seed) {
   MT_REQUIRE(nullptr, h != nullptr, "handle is NULL");
   if (!h->is_reset) return fail(h, MT_ERR_STATE, "mt_reset_done before the first reset");
-  return reset_random_impl(h, seed, episode, 2);
+  return reset_random_impl(h, seed, 0, 2);
 }
 
 // ---- actions ----------------------------------------------------------------------------------
@@ -532,6 +539,46 @@ int mt_rollout(mt_handle h, int n_steps, uint64_t seed, uint32_t step_idx0) {
   return MT_OK;
 }
 
+int mt_rollout_fused(mt_handle h, int n_steps, uint64_t seed, uint32_t step_idx0, int auto_reset) {
+  MT_REQUIRE(nullptr, h != nullptr, "handle is NULL");
+  MT_REQUIRE(h, n_steps >= 0, "n_steps must be >= 0");
+  if (!h->is_reset) return fail(h, MT_ERR_STATE, "mt_rollout_fused before mt_reset / mt_reset_random");
+  if (n_steps == 0) return MT_OK;
+  // The fused kernel keeps the targets of a block in LDS (12*K*256 bytes) and implements the default
+  // trigonometry only; otherwise run the same thing as a sequence of launches.
+  const bool fusable = h->trig == 0 && !h->lds_table && (size_t)3 * h->K * kBlock * sizeof(float) <= 65536;
+  if (!fusable) {
+    for (int s = 0; s < n_steps; ++s) {
+      int rc = mt_step_random(h, seed, step_idx0 + (uint32_t)s);
+      if (rc) return rc;
+      if (auto_reset) {
+        rc = mt_reset_done(h, seed);
+        if (rc) return rc;
+      }
+    }
+    return MT_OK;
+  }
+  MT_HIP(h, hipSetDevice(h->cfg.device));
+  h->args.seed_lo = (uint32_t)seed;
+  h->args.seed_hi = (uint32_t)(seed >> 32);
+  RolloutArgs r{n_steps, step_idx0, auto_reset ? 1u : 0u, h->cfg.radius};
+  if (h->static_kind == 1)
+    launch_rollout_t<Ref4Table>(h, r);
+  else if (h->static_kind == 2)
+    launch_rollout_t<Dh7Table>(h, r);
+  else
+    switch (h->D) {
+      case 2: launch_rollout_t<RtTable<2>>(h, r); break;
+      case 3: launch_rollout_t<RtTable<3>>(h, r); break;
+      case 4: launch_rollout_t<RtTable<4>>(h, r); break;
+      case 5: launch_rollout_t<RtTable<5>>(h, r); break;
+      case 6: launch_rollout_t<RtTable<6>>(h, r); break;
+      case 7: launch_rollout_t<RtTable<7>>(h, r); break;
+      default: launch_rollout_t<RtTable<8>>(h, r); break;
+    }
+  return check_launch(h, "rollout_kernel");
+}
+
 int mt_observe(mt_handle h) {
   MT_REQUIRE(nullptr, h != nullptr, "handle is NULL");
   if (!h->is_reset) return fail(h, MT_ERR_STATE, "mt_observe before reset");
@@ -558,7 +605,9 @@ static int64_t env_major_bytes(mt_handle h, int field) {
     case MT_F_OBS: return n * 3 * h->K * 4;
     case MT_F_ALIVE: return n * h->K;
     case MT_F_REWARD:
-    case MT_F_TOTAL_REWARD: return n * 4;
+    case MT_F_TOTAL_REWARD:
+    case MT_F_EPISODES:
+    case MT_F_LAST_RETURN: return n * 4;
     case MT_F_DONE: return n;
     case MT_F_DONE_BITS: return (n + 63) / 64 * 8;
     case MT_F_EE: return n * 3 * 4;
@@ -594,6 +643,8 @@ int mt_get(mt_handle h, int field, void* dst, int64_t dst_bytes, int is_device) 
     case MT_F_JOINTS: MT_DISPATCH_D(h->D, launch_joints_d, h, (float*)out); break;
     case MT_F_REWARD: direct = true; direct_src = a.reward; break;
     case MT_F_TOTAL_REWARD: direct = true; direct_src = a.total_reward; break;
+    case MT_F_EPISODES: direct = true; direct_src = a.episodes; break;
+    case MT_F_LAST_RETURN: direct = true; direct_src = a.last_return; break;
     case MT_F_DONE: direct = true; direct_src = a.done; break;
     case MT_F_DONE_BITS: direct = true; direct_src = a.done_bits; break;
     default: return fail(h, MT_ERR_INVALID_ARG, "unknown field");

@@ -73,6 +73,8 @@ struct StepArgs {
   uint8_t* done;                  // [ld]
   unsigned long long* done_bits;  // [ld/64]
   float* ee;                      // [3][ld]
+  uint32_t* episodes;             // [ld] episode index of each env (keys its target draws)
+  float* last_return;             // [ld] return of the episode that ended at the last (auto-)reset
   int64_t n, ld, env_base;
   int32_t K, S;
   float tol, inv_sm1;
@@ -234,7 +236,6 @@ __device__ __forceinline__ void step_target(const StepArgs& a, int64_t ld, uint3
 //            1 polynomial sincos at every sub-step (reference-shaped, slowest)
 //            2 hardware v_sin_f32/v_cos_f32 at every interior sub-step
 //            3, 4 DIAGNOSTIC ablations for profiling (MT_FLAG_ABLATE_*): outputs wrong
-//   KPRE   : number of targets whose coordinates are requested before the sub-step loop
 //   LDS    : stage the runtime DH constants in LDS instead of SGPRs (measured
 //            variant; BASELINE.json's north_star asks for the comparison)
 // The first and last pose are always evaluated with the polynomial sincos.
@@ -248,69 +249,38 @@ struct TableMaker<RtTable<D>> {
   static __device__ __forceinline__ RtTable<D> make(const DhConst& c) { return RtTable<D>{c}; }
 };
 
-template <class Tbl, bool SAMPLE, int TRIG, bool LDS, int KPRE>
-__global__ __launch_bounds__(kBlock) void step_kernel(const StepArgs a) {
+// Environment.action_sample for one env (manytor.py:215-217): D integer degrees from Philox blocks.
+template <int D>
+__device__ __forceinline__ void draw_action(uint64_t seed, uint64_t env_id, uint32_t step_idx, float (&act)[D]) {
+#pragma unroll
+  for (int b = 0; b < (D + 3) / 4; ++b) {
+    const u32x4 w = stream_block(seed, env_id, kTagAction, step_idx, (uint32_t)b);
+    const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (4 * b + q < D) act[4 * b + q] = action_from_word(ws[q]);
+  }
+}
+
+// The kinematic part of Environment.action (manytor.py:178-192) for one env: S poses on the straight line in
+// joint space from `g` (previous pose) to `act`.  Returns the elbow and end-effector positions at the final pose
+// and the minimum z of those two frames over all S poses (ground flag <=> zmin < 0).  Shared by step_kernel and
+// rollout_kernel so both evaluate exactly the same arithmetic.
+template <class Tbl, int TRIG>
+__device__ __forceinline__ float route_kinematics(const Tbl& t, int S, float inv_sm1, const float (&g)[Tbl::D],
+                                                  const float (&act)[Tbl::D], float (&el)[3], float (&e)[3]) {
   constexpr int D = Tbl::D;
-  __shared__ DhConst sh;
-  if (LDS) {
-    const float* src = reinterpret_cast<const float*>(&a.dh);
-    float* dst = reinterpret_cast<float*>(&sh);
-    if (threadIdx.x < sizeof(DhConst) / sizeof(float)) dst[threadIdx.x] = src[threadIdx.x];
-    __syncthreads();
-  }
-  const Tbl t = TableMaker<Tbl>::make(LDS ? sh : a.dh);
-
-  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;  // 32-bit lane offset: rows are addressed as uniform base + i
-  if (i >= a.n) return;
-  const int64_t ld = a.ld;
-
-  float g[D], act[D];
-#pragma unroll
-  for (int j = 0; j < D; ++j) g[j] = ldr(a.goals + j * ld, i * 4u);
-  // Everything else this env reads is requested now, so that HBM keeps streaming while the sub-step loop
-  // below runs on the joint angles alone: alive mask, return, and the first KPRE targets (3 rows each).
-  const uint32_t am = ldr(a.alive, i * 4u);
-  const float total_in = ldr(a.total_reward, i * 4u);
-  float pre[KPRE > 0 ? KPRE : 1][3];
-#pragma unroll
-  for (int k = 0; k < KPRE; ++k) {
-    if (k < a.K) {
-      const float* row = a.points + (int64_t)(3 * k) * ld;
-      pre[k][0] = ldr(row, i * 4u);
-      pre[k][1] = ldr(row + ld, i * 4u);
-      pre[k][2] = ldr(row + 2 * ld, i * 4u);
-    }
-  }
-  if (SAMPLE) {
-#pragma unroll
-    for (int b = 0; b < (D + 3) / 4; ++b) {
-      const u32x4 w = stream_block(((uint64_t)a.seed_hi << 32) | a.seed_lo, (uint64_t)(a.env_base + i), kTagAction,
-                                   a.major, (uint32_t)b);
-      const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        if (4 * b + q < D) act[4 * b + q] = action_from_word(ws[q]);
-    }
-    // not stored separately: the action taken becomes `goals` below (manytor.py:184), 4D bytes of traffic saved
-  } else {
-#pragma unroll
-    for (int j = 0; j < D; ++j) act[j] = ldr(a.actions + j * ld, i * 4u);
-  }
-
   // route[k] = goals + k * (action - goals) / (S-1), route[S-1] = action (np.linspace, manytor.py:182)
   float st[D];
 #pragma unroll
-  for (int j = 0; j < D; ++j) st[j] = (act[j] - g[j]) * a.inv_sm1;
+  for (int j = 0; j < D; ++j) st[j] = (act[j] - g[j]) * inv_sm1;
 
-  // ground flag (manytor.py:191): any sub-step with z_elbow < 0 or z_ee < 0  <=>  min over all of them < 0
-  float zmin;
-  float zo, ze;
-  // k = S-1: the action itself, full chain (positions are consumed below)
+  float zmin, zo, ze;
+  // k = S-1: the action itself, full chain (positions are consumed by the caller)
   float sA[D], cA[D], p[D][3];
 #pragma unroll
   for (int j = 0; j < D; ++j) sincos_deg(act[j] + t.off(j), sA[j], cA[j]);
   chain_all<Tbl>(sA, cA, t, p);
-  float el[3], e[3];
 #pragma unroll
   for (int q = 0; q < 3; ++q) {
     el[q] = (D > 2) ? p[D - 2][q] : 0.f;  // joints_coordinates[-2]; row 0 is zeros (manytor.py:189)
@@ -343,8 +313,8 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const StepArgs a) {
     }
     sB[0] = 0.f;
     cB[0] = 1.f;
-    const int nf = (a.S - 1) / 2;   // forward poses k = 1..nf
-    const int nb = a.S - 2 - nf;    // backward poses k = S-2..nf+1   (nb = nf or nf-1)
+    const int nf = (S - 1) / 2;   // forward poses k = 1..nf
+    const int nb = S - 2 - nf;    // backward poses k = S-2..nf+1   (nb = nf or nf-1)
     for (int it = 1; it <= nf; ++it) {
 #pragma unroll
       for (int j = 1; j < D; ++j) {  // rotate by +delta
@@ -369,7 +339,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const StepArgs a) {
     float gq[D];
 #pragma unroll
     for (int j = 0; j < D; ++j) gq[j] = g[j] + t.off(j);
-    for (int k = 1; k < a.S - 1; ++k) {
+    for (int k = 1; k < S - 1; ++k) {
       const float fk = (float)k;
 #pragma unroll
       for (int j = 1; j < D; ++j) {
@@ -383,14 +353,47 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const StepArgs a) {
       zmin = fminf(zmin, fminf(zo, ze));
     }
   }
-  const bool ground = zmin < 0.f;
+  return zmin;
+}
+
+template <class Tbl, bool SAMPLE, int TRIG, bool LDS>
+__global__ __launch_bounds__(kBlock) void step_kernel(const StepArgs a) {
+  constexpr int D = Tbl::D;
+  __shared__ DhConst sh;
+  if (LDS) {
+    const float* src = reinterpret_cast<const float*>(&a.dh);
+    float* dst = reinterpret_cast<float*>(&sh);
+    if (threadIdx.x < sizeof(DhConst) / sizeof(float)) dst[threadIdx.x] = src[threadIdx.x];
+    __syncthreads();
+  }
+  const Tbl t = TableMaker<Tbl>::make(LDS ? sh : a.dh);
+
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;  // 32-bit lane offset: rows are addressed as uniform base + i
+  if (i >= a.n) return;
+  const int64_t ld = a.ld;
+
+  float g[D], act[D];
+#pragma unroll
+  for (int j = 0; j < D; ++j) g[j] = ldr(a.goals + j * ld, i * 4u);
+  // The alive mask and the return are requested now, ahead of the arithmetic that does not need them.
+  // (Requesting the target rows here as well was measured: no gain, -2 waves/SIMD -- profiles/r01_variants.md.)
+  const uint32_t am = ldr(a.alive, i * 4u);
+  const float total_in = ldr(a.total_reward, i * 4u);
+  if (SAMPLE) {
+    // not stored separately: the action taken becomes `goals` below (manytor.py:184), 4D bytes of traffic saved
+    draw_action<D>(((uint64_t)a.seed_hi << 32) | a.seed_lo, (uint64_t)(a.env_base + i), a.major, act);
+  } else {
+#pragma unroll
+    for (int j = 0; j < D; ++j) act[j] = ldr(a.actions + j * ld, i * 4u);
+  }
+
+  float el[3], e[3];
+  const float zmin = route_kinematics<Tbl, TRIG>(t, a.S, a.inv_sm1, g, act, el, e);
+  const bool ground = zmin < 0.f;  // manytor.py:191
 
   // obs2 (before pickup, manytor.py:204) and pickup (manytor.py:206) per target
   uint32_t nam = am;
-#pragma unroll
-  for (int k = 0; k < KPRE; ++k)
-    if (k < a.K) step_target<TRIG == 4>(a, ld, i, k, am, nam, el, e, pre[k][0], pre[k][1], pre[k][2]);
-  for (int k = KPRE; k < a.K; ++k) {
+  for (int k = 0; k < a.K; ++k) {
     if (TRIG == 5) {  // DIAGNOSTIC: arithmetic only, no HBM traffic for targets / observations
       float dist, r, th;
       const float x = (float)(i & 63) + (float)k, y = 3.0f + (float)k, z = 5.0f + g[0];
@@ -437,6 +440,23 @@ __device__ __forceinline__ bool target_candidate(const u32x4& w, float radius, f
   return n2 <= rr;
 }
 
+// Rejection-sample K targets for one env (manytor.py:229-239) and hand each accepted one to `put(k, x, y, z)`.
+// The draw loop is bounded; the tail branch is unreachable in practice (acceptance pi/6 per draw).
+template <class Put>
+__device__ __forceinline__ void draw_targets(uint64_t seed, uint64_t env_id, uint32_t episode, int K, float radius,
+                                             Put&& put) {
+  int cnt = 0;
+  for (uint32_t draw = 0; draw < 4096u && cnt < K; ++draw) {
+    const u32x4 w = stream_block(seed, env_id, kTagTarget, episode, draw);
+    float x, y, z;
+    if (target_candidate(w, radius, x, y, z)) {
+      put(cnt, x, y, z);
+      ++cnt;
+    }
+  }
+  for (; cnt < K; ++cnt) put(cnt, 0.f, 0.f, 0.5f * radius);
+}
+
 // ---------------------------------------------------------------------------
 // action_sample for all envs (manytor.py:215-217), device RNG.
 // ---------------------------------------------------------------------------
@@ -458,7 +478,7 @@ __global__ __launch_bounds__(kBlock) void sample_actions_kernel(float* actions, 
 // ---------------------------------------------------------------------------
 template <int D, bool RANDOM, bool ONLY_DONE>
 __global__ __launch_bounds__(kBlock) void reset_kernel(const StepArgs a, float radius) {
-  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;  // 32-bit lane offset: rows are addressed as uniform base + i
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= a.n) return;
   const int64_t ld = a.ld;
   const bool go = ONLY_DONE ? (a.done[i] != 0) : true;
@@ -472,38 +492,138 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(const StepArgs a, float r
     chain_all<RtTable<D>>(s, c, RtTable<D>{a.dh}, p);  // joints_coordinates at the zero pose, manytor.py:224-225
 #pragma unroll
     for (int q = 0; q < 3; ++q) (a.ee + q * ld)[i] = p[D - 1][q];
+    a.last_return[i] = a.total_reward[i];
     a.total_reward[i] = 0.f;
     a.reward[i] = 0;
     a.done[i] = 0;
     a.alive[i] = (a.K >= 32) ? 0xFFFFFFFFu : ((1u << a.K) - 1u);
+    // full reset: the caller names the episode; re-arm of a finished env: its own counter advances by one
+    const uint32_t episode = ONLY_DONE ? a.episodes[i] + 1u : a.major;
+    a.episodes[i] = episode;
     if (RANDOM) {
       // manytor.py:229-239: uniform in the cube, keep z >= 0 and |p| <= radius.  z is drawn from
       // [0, R) directly (same conditional law).  fp32, one rounding per op, mirrored by oracle/philox_ref.py.
       const uint64_t seed = ((uint64_t)a.seed_hi << 32) | a.seed_lo;
-      int cnt = 0;
-      for (uint32_t draw = 0; draw < 4096u && cnt < a.K; ++draw) {
-        const u32x4 w = stream_block(seed, (uint64_t)(a.env_base + i), kTagTarget, a.major, draw);
-        float x, y, z;
-        if (target_candidate(w, radius, x, y, z)) {
-          float* row = a.points + (int64_t)(3 * cnt) * ld;
-          row[i] = x;
-          (row + ld)[i] = y;
-          (row + 2 * ld)[i] = z;
-          ++cnt;
-        }
-      }
-      for (; cnt < a.K; ++cnt) {  // unreachable in practice (p < 1e-1000); keeps the loop bounded
-        float* row = a.points + (int64_t)(3 * cnt) * ld;
-        row[i] = 0.f;
-        (row + ld)[i] = 0.f;
-        (row + 2 * ld)[i] = 0.5f * radius;
-      }
+      draw_targets(seed, (uint64_t)(a.env_base + i), episode, a.K, radius, [&](int k, float x, float y, float z) {
+        float* row = a.points + (int64_t)(3 * k) * ld;
+        row[i] = x;
+        (row + ld)[i] = y;
+        (row + 2 * ld)[i] = z;
+      });
     }
   }
-  if ((threadIdx.x & 63) == 0) a.done_bits[i >> 6] = 0ull;  // every env of the wave has done == 0 now ...
-  if (ONLY_DONE) {
-    // ... unless it was not re-armed and is not done either: done stays 0; nothing to do.
+  if ((threadIdx.x & 63) == 0) a.done_bits[i >> 6] = 0ull;  // every env of the wave has done == 0 now
+}
+
+// ---------------------------------------------------------------------------
+// rollout: T consecutive Environment.step()s with in-kernel random actions in ONE launch (the inner loop of
+// test_multi.py:19-21), optionally re-arming an env the moment it finishes.
+// Joint angles, alive mask and return stay in registers between steps and the env's targets stay in LDS
+// ([3K][256] floats per block, one column per thread, conflict-free), so per step only the outputs are
+// written: obs 12K + reward 4 + done 1 + ee 12 bytes per env instead of the 233 a single-step launch moves.
+// Per step it runs exactly the arithmetic of step_kernel (shared device functions), so
+//   rollout(T)  ==  T x step_random          (auto_reset = 0)
+//   rollout(T)  ==  T x (step_random; reset_done)   (auto_reset = 1, state fields)
+// bit for bit; tests/test_gpu_parity.py checks both.
+// ---------------------------------------------------------------------------
+struct RolloutArgs {
+  int32_t T;
+  uint32_t step0;
+  uint32_t auto_reset;
+  float radius;
+};
+
+template <class Tbl>
+__global__ __launch_bounds__(kBlock) void rollout_kernel(const StepArgs a, const RolloutArgs r) {
+  extern __shared__ float tile[];  // [3K][kBlock]
+  constexpr int D = Tbl::D;
+  const Tbl t = TableMaker<Tbl>::make(a.dh);
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= a.n) return;  // no barrier below: every thread touches only its own LDS column
+  const int64_t ld = a.ld;
+  const uint64_t seed = ((uint64_t)a.seed_hi << 32) | a.seed_lo;
+  const uint64_t env_id = (uint64_t)(a.env_base + i);
+  float* col = tile + threadIdx.x;
+
+  float g[D];
+#pragma unroll
+  for (int j = 0; j < D; ++j) g[j] = ldr(a.goals + j * ld, i * 4u);
+  uint32_t am = ldr(a.alive, i * 4u);
+  float total = ldr(a.total_reward, i * 4u);
+  uint32_t episode = r.auto_reset ? ldr(a.episodes, i * 4u) : 0u;
+  float last_ret = 0.f;
+  bool ended = false, dirty = false;
+  for (int k = 0; k < 3 * a.K; ++k) col[k * kBlock] = ldr(a.points + (int64_t)k * ld, i * 4u);
+  const uint32_t all_alive = (a.K >= 32) ? 0xFFFFFFFFu : ((1u << a.K) - 1u);
+
+  for (int s = 0; s < r.T; ++s) {
+    float act[D], el[3], e[3];
+    draw_action<D>(seed, env_id, r.step0 + (uint32_t)s, act);
+    const float zmin = route_kinematics<Tbl, 0>(t, a.S, a.inv_sm1, g, act, el, e);
+    const bool ground = zmin < 0.f;
+
+    uint32_t nam = am;
+    for (int k = 0; k < a.K; ++k) {
+      float* pk = col + 3 * k * kBlock;
+      const float x = pk[0], y = pk[kBlock], z = pk[2 * kBlock];
+      const bool al = (am >> k) & 1u;
+      float dist = 0.f, rr = 0.f, th = 0.f;
+      if (al) {
+        observe_target(el, x, y, z, dist, rr, th);
+        if (within_box(e, x, y, z, a.tol)) nam &= ~(1u << k);
+      } else if ((x != 0.f) | (y != 0.f) | (z != 0.f)) {  // manytor.py:148
+        pk[0] = 0.f;
+        pk[kBlock] = 0.f;
+        pk[2 * kBlock] = 0.f;
+        dirty = true;
+      }
+      float* orow = a.obs + (int64_t)(3 * k) * ld;
+      str_stream(orow, i * 4u, dist);
+      str_stream(orow + ld, i * 4u, rr);
+      str_stream(orow + 2 * ld, i * 4u, th);
+    }
+    const int32_t rew = ground ? -1 : ((nam != am) ? 1 : 0);
+    bool done = (nam == 0u);
+    if (a.flags & MT_FLAG_TERMINATE_ON_GROUND) done |= ground;
+    total += (float)rew;
+    am = nam;
+#pragma unroll
+    for (int j = 0; j < D; ++j) g[j] = act[j];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) str_stream(a.ee + q * ld, i * 4u, e[q]);
+    str_stream(a.reward, i * 4u, rew);
+    str_stream(a.done, i, (uint8_t)(done ? 1 : 0));
+    const unsigned long long bits = __ballot(done);
+    if ((threadIdx.x & 63) == 0) a.done_bits[i >> 6] = bits;
+
+    if (done && r.auto_reset) {  // re-arm: what reset_kernel<.., RANDOM, ONLY_DONE> does in a separate launch
+      last_ret = total;
+      ended = true;
+      total = 0.f;
+      am = all_alive;
+      episode += 1u;
+#pragma unroll
+      for (int j = 0; j < D; ++j) g[j] = 0.f;
+      draw_targets(seed, env_id, episode, a.K, r.radius, [&](int k, float x, float y, float z) {
+        float* pk = col + 3 * k * kBlock;
+        pk[0] = x;
+        pk[kBlock] = y;
+        pk[2 * kBlock] = z;
+      });
+      dirty = true;
+    }
   }
+
+#pragma unroll
+  for (int j = 0; j < D; ++j) str(a.goals + j * ld, i * 4u, g[j]);
+  str(a.alive, i * 4u, am);
+  str(a.total_reward, i * 4u, total);
+  if (ended) {
+    str(a.episodes, i * 4u, episode);
+    str(a.last_return, i * 4u, last_ret);
+  }
+  if (dirty)
+    for (int k = 0; k < 3 * a.K; ++k) str(a.points + (int64_t)k * ld, i * 4u, col[k * kBlock]);
 }
 
 // ---------------------------------------------------------------------------

@@ -63,7 +63,7 @@ class StepEngine:
 
     def __init__(self, n_envs, obj_number=10, dh_table=REF_DH_TABLE, substeps=25, pickup_tol=8.0, radius=51.3,
                  device=0, env_id_base=0, terminate_on_ground=False, hw_trig=False, dh_in_lds=False,
-                 direct_trig=False, specialize=True, ablate=0, prefetch=None):
+                 direct_trig=False, specialize=True, ablate=0):
         self._lib = L.load()
         table = np.asarray(dh_table, dtype=np.float64)
         if table.ndim != 2 or table.shape[1] != 4:
@@ -86,7 +86,6 @@ class StepEngine:
         cfg.flags = ((L.FLAG_TERMINATE_ON_GROUND if terminate_on_ground else 0) | (L.FLAG_HW_TRIG if hw_trig else 0)
                      | (L.FLAG_DH_IN_LDS if dh_in_lds else 0) | (L.FLAG_DIRECT_TRIG if direct_trig else 0)
                      | (0 if specialize else L.FLAG_NO_SPECIALIZE)
-                     | {None: 0, 0: 0, 4: L.FLAG_PREFETCH4, 8: L.FLAG_PREFETCH8}[prefetch]
                      | (L.FLAG_ABLATE_LOOP if ablate in (1, 2) else 0) | (L.FLAG_ABLATE_OBS if ablate in (2, 3) else 0))
         cfg.pickup_tol = float(pickup_tol)
         cfg.radius = float(radius)
@@ -172,8 +171,9 @@ class StepEngine:
         self._call(self._lib.mt_reset_random, C.c_uint64(seed), C.c_uint32(episode))
         self.version += 1
 
-    def reset_done(self, seed=0x5EED, episode=0):
-        self._call(self._lib.mt_reset_done, C.c_uint64(seed), C.c_uint32(episode))
+    def reset_done(self, seed=0x5EED):
+        """Re-arm the envs whose done flag is set (new targets keyed by their own episode counter)."""
+        self._call(self._lib.mt_reset_done, C.c_uint64(seed))
         self.version += 1
 
     # ---- actions ------------------------------------------------------------------------------
@@ -228,6 +228,12 @@ class StepEngine:
         self._call(self._lib.mt_rollout, int(n_steps), C.c_uint64(seed), C.c_uint32(step_idx0))
         self.version += 1
 
+    def rollout_fused(self, n_steps, seed=0x5EED, step_idx0=0, auto_reset=False):
+        """n_steps random-action steps in ONE launch (state in registers / LDS between steps)."""
+        self._call(self._lib.mt_rollout_fused, int(n_steps), C.c_uint64(seed), C.c_uint32(step_idx0),
+                   1 if auto_reset else 0)
+        self.version += 1
+
     def observe(self):
         """Environment.get_observations (manytor.py:141-153); result in field OBS."""
         self._call(self._lib.mt_observe)
@@ -246,6 +252,7 @@ class StepEngine:
             L.F_ALIVE: ((n, k), np.uint8), L.F_OBS: ((n, 3 * k), np.float32), L.F_REWARD: ((n,), np.int32),
             L.F_DONE: ((n,), np.uint8), L.F_DONE_BITS: (((n + 63) // 64,), np.uint64), L.F_EE: ((n, 3), np.float32),
             L.F_TOTAL_REWARD: ((n,), np.float32), L.F_JOINTS: ((n, d, 3), np.float32),
+            L.F_EPISODES: ((n,), np.uint32), L.F_LAST_RETURN: ((n,), np.float32),
         }[field]
 
     def get(self, field) -> np.ndarray:
@@ -317,6 +324,12 @@ class StepEngine:
 
     def joints_coordinates(self):
         return self.get(L.F_JOINTS)
+
+    def episodes(self):
+        return self.get(L.F_EPISODES)
+
+    def last_return(self):
+        return self.get(L.F_LAST_RETURN)
 
     def actions(self):
         return self.get(L.F_ACTIONS)

@@ -490,21 +490,74 @@ def test_full_size_properties(m, mo, n, table_name):
 
 
 def test_reset_done_rearms_only_finished_envs(m):
+    from oracle import philox_ref as px
     n, k = 4096, 1
     eng = m.StepEngine(n, k, pickup_tol=30.0)
-    eng.reset_random(3, 0)
+    eng.reset_random(3, 5)
+    assert np.all(eng.episodes() == 5)
     for t in range(6):
         eng.step_random(3, t)
     done = eng.done()
     assert 0 < done.sum() < n
     goals, total, pts = eng.goals(), eng.total_reward(), eng.points()
-    eng.reset_done(3, 1)
+    eng.reset_done(3)
     assert eng.alives()[done].all() and not eng.done().any() and not eng.done_bits().any()
     assert np.all(eng.goals()[done] == 0) and np.all(eng.total_reward()[done] == 0)
+    np.testing.assert_array_equal(eng.episodes(), np.where(done, 6, 5))            # own counter advanced
+    np.testing.assert_array_equal(eng.last_return()[done], total[done])              # finished return kept
     np.testing.assert_array_equal(eng.goals()[~done], goals[~done])
     np.testing.assert_array_equal(eng.total_reward()[~done], total[~done])
     np.testing.assert_array_equal(eng.points()[~done], pts[~done])
-    assert (np.abs(eng.points()[done]).sum(axis=(1, 2)) > 0).all()
+    fresh = px.sample_targets(3, np.arange(n, dtype=np.uint64), 6, k, 51.3)          # keyed by (env, episode 6)
+    np.testing.assert_array_equal(eng.points()[done], fresh[done])
+
+
+STATE_FIELDS = ("F_GOALS", "F_ALIVE", "F_TOTAL_REWARD", "F_POINTS", "F_EPISODES", "F_LAST_RETURN")
+STEP_FIELDS = ("F_OBS", "F_REWARD", "F_DONE", "F_EE", "F_DONE_BITS")
+
+
+@pytest.mark.parametrize("cfg", [dict(n=10000, k=7, table="ref"), dict(n=3000, k=10, table="ref"),
+                                 dict(n=2048, k=7, table="dh7"), dict(n=1000, k=3, table="rt5"),
+                                 dict(n=777, k=32, table="ref")])
+def test_fused_rollout_equals_launch_per_step(m, cfg):
+    """mt_rollout_fused(T) is bit-identical to T x mt_step_random (state in registers/LDS vs HBM round trips)."""
+    rng = np.random.RandomState(1)
+    table = {"ref": m.REF_DH_TABLE, "dh7": m.DH7_TABLE,
+             "rt5": np.column_stack([rng.uniform(0, 9, 5), rng.choice([-np.pi / 2, 0.3, np.pi / 2], 5),
+                                     rng.uniform(2, 12, 5), np.zeros(5)])}[cfg["table"]]
+    radius = 92.6 if cfg["table"] == "dh7" else 51.3
+    a = m.StepEngine(cfg["n"], cfg["k"], dh_table=table, radius=radius)
+    b = m.StepEngine(cfg["n"], cfg["k"], dh_table=table, radius=radius)
+    for e in (a, b):
+        e.reset_random(21, 0)
+    for t0, T in ((0, 1), (1, 7), (8, 25)):
+        for t in range(t0, t0 + T):
+            a.step_random(21, t)
+        b.rollout_fused(T, 21, t0)
+        for f in STATE_FIELDS + STEP_FIELDS:
+            np.testing.assert_array_equal(a.get(getattr(m.lib, f)), b.get(getattr(m.lib, f)), err_msg=f)
+
+
+def test_fused_rollout_with_auto_reset_equals_step_plus_reset_done(m):
+    n, k = 20000, 2
+    a = m.StepEngine(n, k, pickup_tol=25.0)
+    b = m.StepEngine(n, k, pickup_tol=25.0)
+    for e in (a, b):
+        e.reset_random(9, 0)
+    T = 30
+    for t in range(T):
+        a.step_random(9, t)
+        if t == T - 1:
+            last = {f: a.get(getattr(m.lib, f)) for f in STEP_FIELDS}
+        a.reset_done(9)
+    b.rollout_fused(T, 9, 0, auto_reset=True)
+    for f in STATE_FIELDS:
+        np.testing.assert_array_equal(a.get(getattr(m.lib, f)), b.get(getattr(m.lib, f)), err_msg=f)
+    for f in STEP_FIELDS:                                   # the last step's outputs survive in the fused path
+        np.testing.assert_array_equal(last[f], b.get(getattr(m.lib, f)), err_msg=f)
+    ep = b.episodes()
+    assert ep.max() >= 2 and (ep == 0).any()                # some envs finished several episodes, some none
+    assert np.all(b.last_return()[ep > 0] == np.round(b.last_return()[ep > 0]))
 
 
 # --------------------------------------------------------------------------- boundary behaviour
