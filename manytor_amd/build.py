@@ -44,6 +44,8 @@ def build_library(force: bool = False, verbose: bool = False, extra_flags=()) ->
         # gfx950 issues v_pk_*_f32 at half the rate of scalar VALU ops, so SLP-packing adjacent fp32 math only adds
         # register shuffles (measured: sub-step loop 66 -> 43 instructions, 72 -> 58 VGPRs without it)
         "-fno-slp-vectorize",
+        # FMAs are written out in the source; no implicit contraction, so every kernel rounds a formula identically
+        "-ffp-contract=off",
         *extra_flags,
         *[os.path.join(CSRC, s) for s in SOURCES],
         "-o", LIB_PATH + ".tmp",

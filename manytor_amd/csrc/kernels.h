@@ -144,12 +144,12 @@ __device__ __forceinline__ void chain_all(const float (&s)[Tbl::D], const float 
   for (int j = 0; j < D; ++j) {
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
-      const float nx = X[q] * c[j] + Y[q] * s[j];
-      const float tt = Y[q] * c[j] - X[q] * s[j];
-      o[q] += t.a(j) * nx + t.d(j) * Z[q];
+      const float nx = pfma(X[q], c[j], pmul(Y[q], s[j]));
+      const float tt = pfma(Y[q], c[j], -pmul(X[q], s[j]));
+      o[q] = pfma(t.a(j), nx, pfma(t.d(j), Z[q], o[q]));
       X[q] = nx;
-      Y[q] = tt * t.ca(j) + Z[q] * t.sa(j);
-      Z[q] = Z[q] * t.ca(j) - tt * t.sa(j);
+      Y[q] = pfma(tt, t.ca(j), pmul(Z[q], t.sa(j)));
+      Z[q] = pfma(Z[q], t.ca(j), -pmul(tt, t.sa(j)));
       p[j][q] = o[q];
     }
   }
@@ -166,12 +166,12 @@ __device__ __forceinline__ void chain_z(const float (&s)[Tbl::D], const float (&
   z_obs = 0.f;
 #pragma unroll
   for (int j = 0; j < D; ++j) {
-    const float nx = x * c[j] + y * s[j];
-    const float tt = y * c[j] - x * s[j];
-    o += t.a(j) * nx + t.d(j) * z;
+    const float nx = pfma(x, c[j], pmul(y, s[j]));
+    const float tt = pfma(y, c[j], -pmul(x, s[j]));
+    o = pfma(t.a(j), nx, pfma(t.d(j), z, o));
     x = nx;
-    y = tt * t.ca(j) + z * t.sa(j);
-    z = z * t.ca(j) - tt * t.sa(j);
+    y = pfma(tt, t.ca(j), pmul(z, t.sa(j)));
+    z = pfma(z, t.ca(j), -pmul(tt, t.sa(j)));
     if (j == D - 2 && D > 2) z_obs = o;
   }
   z_ee = o;
@@ -182,9 +182,9 @@ __device__ __forceinline__ void chain_z(const float (&s)[Tbl::D], const float (&
 __device__ __forceinline__ void observe_target(const float (&el)[3], float x, float y, float z, float& dist, float& r,
                                                float& th) {
   const float m0 = fabsf(el[0] - x), m1 = fabsf(el[1] - y), m2 = fabsf(el[2] - z);
-  const float h2 = m0 * m0 + m1 * m1;
+  const float h2 = __builtin_fmaf(m0, m0, m1 * m1);
   const float h = __builtin_amdgcn_sqrtf(h2);            // v_sqrt_f32, 1 ulp: no refinement sequence
-  dist = __builtin_amdgcn_sqrtf(h2 + m2 * m2);
+  dist = __builtin_amdgcn_sqrtf(__builtin_fmaf(m2, m2, h2));
   r = atan2_deg_q1(m0, m1);
   th = atan2_deg_q1(h, m2);
 }
@@ -318,8 +318,8 @@ __device__ __forceinline__ float route_kinematics(const Tbl& t, int S, float inv
     for (int it = 1; it <= nf; ++it) {
 #pragma unroll
       for (int j = 1; j < D; ++j) {  // rotate by +delta
-        const float c2 = cF[j] * cd[j] - sF[j] * sd[j];
-        sF[j] = sF[j] * cd[j] + cF[j] * sd[j];
+        const float c2 = __builtin_fmaf(cF[j], cd[j], -(sF[j] * sd[j]));
+        sF[j] = __builtin_fmaf(sF[j], cd[j], cF[j] * sd[j]);
         cF[j] = c2;
       }
       chain_z<Tbl>(sF, cF, t, zo, ze);
@@ -327,8 +327,8 @@ __device__ __forceinline__ float route_kinematics(const Tbl& t, int S, float inv
       if (it <= nb) {
 #pragma unroll
         for (int j = 1; j < D; ++j) {  // rotate by -delta
-          const float c2 = cB[j] * cd[j] + sB[j] * sd[j];
-          sB[j] = sB[j] * cd[j] - cB[j] * sd[j];
+          const float c2 = __builtin_fmaf(cB[j], cd[j], sB[j] * sd[j]);
+          sB[j] = __builtin_fmaf(sB[j], cd[j], -(cB[j] * sd[j]));
           cB[j] = c2;
         }
         chain_z<Tbl>(sB, cB, t, zo, ze);
@@ -767,12 +767,12 @@ __global__ __launch_bounds__(kBlock) void fk_kernel(const FkArgs a) {
     float s, c;
     sincos_deg(ang + a.dh.off_deg[j], s, c);
     for (int q = 0; q < 3; ++q) {
-      const float nx = X[q] * c + Y[q] * s;
-      const float tt = Y[q] * c - X[q] * s;
-      o[q] += a.dh.a[j] * nx + a.dh.d[j] * Z[q];
+      const float nx = __builtin_fmaf(X[q], c, Y[q] * s);
+      const float tt = __builtin_fmaf(Y[q], c, -(X[q] * s));
+      o[q] = __builtin_fmaf(a.dh.a[j], nx, __builtin_fmaf(a.dh.d[j], Z[q], o[q]));
       X[q] = nx;
-      Y[q] = tt * a.dh.ca[j] + Z[q] * a.dh.sa[j];
-      Z[q] = Z[q] * a.dh.ca[j] - tt * a.dh.sa[j];
+      Y[q] = __builtin_fmaf(tt, a.dh.ca[j], Z[q] * a.dh.sa[j]);
+      Z[q] = __builtin_fmaf(Z[q], a.dh.ca[j], -(tt * a.dh.sa[j]));
     }
   }
   float* m = a.out + (int64_t)i * 16;
@@ -793,7 +793,7 @@ __global__ __launch_bounds__(kBlock) void r_theta_kernel(const float* v1, const 
   if (i >= n) return;
   const int64_t b3 = 3 * (int64_t)i;
   const float d0 = fabsf(v1[b3] - v2[b3]), d1 = fabsf(v1[b3 + 1] - v2[b3 + 1]), d2 = fabsf(v1[b3 + 2] - v2[b3 + 2]);
-  const float h = __builtin_amdgcn_sqrtf(d0 * d0 + d1 * d1);
+  const float h = __builtin_amdgcn_sqrtf(__builtin_fmaf(d0, d0, d1 * d1));
   out[2 * (int64_t)i] = atan2_deg_q1(d0, d1);
   out[2 * (int64_t)i + 1] = atan2_deg_q1(h, d2);
 }

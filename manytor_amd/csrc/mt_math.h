@@ -10,6 +10,40 @@
 
 namespace mt {
 
+// Every kernel is compiled with -ffp-contract=off and spells its fused multiply-adds out, so that a formula
+// rounds the same way wherever it is inlined: step_kernel (both action sources), rollout_kernel, observe_kernel
+// ... produce bit-identical numbers for the same inputs by construction, not by luck of instruction selection.
+// pmul / pfma additionally drop products with an operand that is a compile-time 0 or +-1 (the entries of a
+// static DH table and of the identity the chain starts from).
+__device__ __forceinline__ float pmul(float a, float b) {
+  if (__builtin_constant_p(a)) {
+    if (a == 0.f) return 0.f;
+    if (a == 1.f) return b;
+    if (a == -1.f) return -b;
+  }
+  if (__builtin_constant_p(b)) {
+    if (b == 0.f) return 0.f;
+    if (b == 1.f) return a;
+    if (b == -1.f) return -a;
+  }
+  return a * b;
+}
+// a * b + c
+__device__ __forceinline__ float pfma(float a, float b, float c) {
+  if (__builtin_constant_p(a)) {
+    if (a == 0.f) return c;
+    if (a == 1.f) return b + c;
+    if (a == -1.f) return c - b;
+  }
+  if (__builtin_constant_p(b)) {
+    if (b == 0.f) return c;
+    if (b == 1.f) return a + c;
+    if (b == -1.f) return c - a;
+  }
+  if (__builtin_constant_p(c) && c == 0.f) return a * b;
+  return __builtin_fmaf(a, b, c);
+}
+
 // sin and cos of x degrees, |x| <= 720 or so.  Max abs error ~8e-8.
 __device__ __forceinline__ void sincos_deg(float x, float& s, float& c) {
   const float q = __builtin_rintf(x * (1.0f / 90.0f));
