@@ -182,6 +182,11 @@ MT_API int mt_timer_stop(mt_handle h, float* elapsed_ms);
  * Host pointers in, host pointers out; run on `device`. */
 MT_API int mt_fk_batch(int device, const float* dh_table, int dof, int mode, const float* angles, int angles_in_radians,
                 int64_t n, float* out_mat16);
+/* joints_coordinates at each of the `substeps` poses of the straight joint-space route prev -> action
+ * (manytor.py:182-190; what the reference appends to `trajectory` and streams to its viewer): host (n, dof) in,
+ * host (n, substeps, dof, 3) out.  Off the step path; meant for the few envs one draws or logs. */
+MT_API int mt_route_trace(int device, const float* dh_table, int dof, int substeps, const float* prev,
+                          const float* action, int64_t n, float* out);
 MT_API int mt_r_theta_batch(int device, const float* v1, const float* v2, int64_t n, float* out_r_theta);
 
 #ifdef __cplusplus

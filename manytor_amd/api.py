@@ -20,7 +20,8 @@ import numpy as np
 
 from . import _lib as L
 from . import rng as _rng
-from .engine import REF_DH_TABLE, StepEngine, fk_batch, r_theta_batch
+from .engine import REF_DH_TABLE, StepEngine, fk_batch, r_theta_batch, route_trace
+from .viewer import ViewerLink
 
 HOST = "localhost"     # manytor.py:9   (viewer address; rendering itself is out of scope here)
 PORT = 5001            # manytor.py:10
@@ -135,9 +136,14 @@ class Multienv:
 
     def __init__(self, env_shape=(1, 2), obj_number=5, *, rng="numpy", seed=0x5EED, device=0, env_id_base=0,
                  dh_table=REF_DH_TABLE, substeps=25, pickup_tol=8.0, radius=51.3, terminate_on_ground=False,
-                 materialize="auto", **engine_kwargs):
+                 materialize="auto", viewer=None, view_envs=16, **engine_kwargs):
         if rng not in ("numpy", "device"):
             raise ValueError("rng must be 'numpy' or 'device'")
+        self._viewer = ViewerLink(*viewer) if isinstance(viewer, (tuple, list)) else viewer
+        self._view_envs = int(view_envs)
+        self._fresh = True
+        self._dh_table = dh_table
+        self._substeps = substeps
         self.env_shape = env_shape
         self.env_number = env_shape[0] * env_shape[1]
         self.obj_number = obj_number
@@ -167,9 +173,24 @@ class Multienv:
         return hit[1]
 
     def render(self, stop_render=False):
-        """manytor.py:84-104.  The vispy/UDP viewer is out of scope; only the flag is kept so that
-        the control flow of test_multi.py:25-28 is unchanged."""
+        """manytor.py:84-104.  Keeps the `rendering` flag (control flow of test_multi.py:25-28).  If a ViewerLink was
+        given (`viewer=(host, port)`), the reference's init / stop datagrams are sent and, while rendering, every
+        step streams the sub-step frames of the first `view_envs` envs (manytor_amd/viewer.py).  The viewer process
+        itself is never spawned here."""
         self.rendering = not stop_render
+        if self._viewer is not None:
+            if stop_render:
+                self._viewer.stop()
+            else:
+                self._viewer.init(min(self.env_number, self._view_envs), self.obj_number, self.env_shape)
+
+    def _stream_frames(self, prev_goals):
+        m = min(self.env_number, self._view_envs)
+        goals = self._cached(L.F_GOALS)[:m]
+        traces = route_trace(prev_goals[:m], goals, dh_table=self._dh_table, substeps=self._substeps,
+                             device=self._engine.device)
+        self._viewer.frames(list(range(m)), traces, self._cached(L.F_POINTS)[:m], first=self._fresh)
+        self._fresh = False
 
     def reset(self, returnable=False):
         """manytor.py:106-109."""
@@ -178,6 +199,9 @@ class Multienv:
         else:
             self._engine.reset_random(self.seed, self._episode)
         self._episode += 1
+        self._fresh = True
+        if self.rendering and self._viewer is not None:
+            self._viewer.clear()                       # manytor.py:246-249
         if returnable:
             self._engine.observe()
             if self._materialize:
@@ -196,11 +220,15 @@ class Multienv:
 
     def step(self, action):
         """manytor.py:115-122 -> (obs2_list, reward_list, done_list)."""
+        streaming = self.rendering and self._viewer is not None
+        prev = self._cached(L.F_GOALS).copy() if streaming else None
         if action is DEVICE_ACTIONS:
             self._engine.step()
         else:
             self._engine.step(action)
         self._step_idx += 1
+        if streaming:
+            self._stream_frames(prev)
         if self._materialize:
             e = self._engine
             return ([row.astype(np.float64) for row in e.obs()], [int(r) for r in e.reward()],
@@ -228,9 +256,17 @@ class Environment:
     """``Environment(obj_number=10, index=0)``: one arm = a batch of one on the same engine."""
 
     def __init__(self, obj_number=10, index=0, *, rng="numpy", seed=0x5EED, device=0, dh_table=REF_DH_TABLE,
-                 substeps=25, pickup_tol=8.0, radius=51.3, terminate_on_ground=False):
+                 substeps=25, pickup_tol=8.0, radius=51.3, terminate_on_ground=False, keep_trajectory=True,
+                 viewer=None):
         if rng not in ("numpy", "device"):
             raise ValueError("rng must be 'numpy' or 'device'")
+        self._viewer = ViewerLink(*viewer) if isinstance(viewer, (tuple, list)) else viewer
+        self._keep_trajectory = bool(keep_trajectory)
+        self._dh_table = dh_table
+        self._substeps = substeps
+        self._fresh = True
+        # manytor.py:135: end-effector trace, one row per sub-step, seeded with (0, 0, 51.3)
+        self.trajectory = np.array([0.0, 0.0, 51.3])
         self.id = index
         self.obj_number = obj_number
         self.rendering = False
@@ -273,12 +309,28 @@ class Environment:
         self._engine.check_done()
         return bool(self._engine.done()[0])
 
+    def _after_route(self, prev, action):
+        """Host-side bookkeeping the reference does per sub-step (manytor.py:190, :194-202): trajectory rows and
+        viewer frames, from one route_trace call after the step has run."""
+        streaming = self.rendering and self._viewer is not None
+        if not (self._keep_trajectory or streaming):
+            return
+        trace = route_trace(prev, action, dh_table=self._dh_table, substeps=self._substeps, device=self._engine.device)
+        if self._keep_trajectory:
+            self.trajectory = np.vstack((self.trajectory, trace[0, :, -1, :].astype(np.float64)))
+        if streaming:
+            self._viewer.frames([self.id], trace, self._engine.points(), first=self._fresh)
+            self._fresh = False
+
     def action(self, action, obs=None):
         """manytor.py:175-213 -> (reward, obs2).  Like the reference it does not add to total_reward;
         the fused step kernel does, so the increment is taken back out."""
         before = self._engine.total_reward()
-        self._engine.step(np.asarray(action, dtype=np.float64).reshape(1, -1))
+        prev = self._engine.goals()
+        act = np.asarray(action, dtype=np.float64).reshape(1, -1)
+        self._engine.step(act)
         self._engine.set(L.F_TOTAL_REWARD, before)
+        self._after_route(prev, act)
         return int(self._engine.reward()[0]), self._engine.obs()[0].astype(np.float64)
 
     def action_sample(self):
@@ -295,19 +347,33 @@ class Environment:
         else:
             self._engine.reset_random(self.seed, self._episode)
         self._episode += 1
+        self.trajectory = np.array([0.0, 0.0, 51.3])      # manytor.py:223
+        self._fresh = True
+        if self.rendering and self._viewer is not None:
+            self._viewer.clear()                           # manytor.py:246-249
         if returnable:
             return self.get_observations()
 
     def step(self, action):
         """manytor.py:255-260 -> (obs2, reward, done)."""
-        self._engine.step(np.asarray(action, dtype=np.float64).reshape(1, -1))
+        prev = self._engine.goals() if (self._keep_trajectory or (self.rendering and self._viewer)) else None
+        act = np.asarray(action, dtype=np.float64).reshape(1, -1)
+        self._engine.step(act)
         self._step_idx += 1
+        if prev is not None:
+            self._after_route(prev, act)
         e = self._engine
         return e.obs()[0].astype(np.float64), int(e.reward()[0]), bool(e.done()[0])
 
     def render(self, stop_render=False, multienv=False):
-        """manytor.py:262-283: viewer out of scope, flag only."""
+        """manytor.py:262-283.  Flag always; init / stop datagrams if a ViewerLink was given (`viewer=(host, port)`).
+        The viewer process is never spawned here."""
         self.rendering = not stop_render
+        if self._viewer is not None and not multienv:
+            if stop_render:
+                self._viewer.stop()
+            else:
+                self._viewer.init(1, self.obj_number)
 
     def close(self):
         self._engine.close()

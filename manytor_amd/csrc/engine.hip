@@ -746,6 +746,32 @@ int mt_fk_batch(int device, const float* dh_table, int dof, int mode, const floa
   return rc;
 }
 
+int mt_route_trace(int device, const float* dh_table, int dof, int substeps, const float* prev, const float* action,
+                   int64_t n, float* out) {
+  MT_REQUIRE(nullptr, dh_table && prev && action && out, "NULL argument");
+  MT_REQUIRE(nullptr, dof >= 2 && dof <= MT_MAX_DOF && substeps >= 2, "dof/substeps out of range");
+  MT_REQUIRE(nullptr, n >= 1 && n * substeps < ((int64_t)1 << 31), "n out of range");
+  MT_HIP(nullptr, hipSetDevice(device));
+  const size_t in_b = (size_t)n * dof * 4, out_b = (size_t)n * substeps * dof * 3 * 4;
+  char* d = nullptr;
+  if (hipMalloc(&d, 2 * in_b + out_b) != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(nullptr, MT_ERR_ALLOC, "hipMalloc failed");
+  }
+  int rc = MT_OK;
+  TraceArgs a{(const float*)d, (const float*)(d + in_b), (float*)(d + 2 * in_b), n, dof, substeps, make_dh(dh_table, dof)};
+  hipError_t e = hipMemcpy(d, prev, in_b, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d + in_b, action, in_b, hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(route_trace_kernel, grid_for(n * substeps), dim3(kBlock), 0, 0, a);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpy(out, d + 2 * in_b, out_b, hipMemcpyDeviceToHost);
+  if (e != hipSuccess) rc = fail(nullptr, MT_ERR_HIP, std::string("mt_route_trace: ") + hipGetErrorString(e));
+  (void)hipFree(d);
+  return rc;
+}
+
 int mt_r_theta_batch(int device, const float* v1, const float* v2, int64_t n, float* out_r_theta) {
   MT_REQUIRE(nullptr, v1 && v2 && out_r_theta, "NULL argument");
   MT_REQUIRE(nullptr, n >= 1, "n must be >= 1");

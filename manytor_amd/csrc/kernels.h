@@ -788,6 +788,44 @@ __global__ __launch_bounds__(kBlock) void fk_kernel(const FkArgs a) {
   m[15] = 1.f;
 }
 
+// Sub-step trajectory export: joints_coordinates at every one of the S poses of the
+// route prev -> action (manytor.py:182-190), for a handful of envs the host wants to draw or log.  One thread per
+// (env, sub-step); every pose gets the full polynomial sincos (this is not the timed path).
+struct TraceArgs {
+  const float* prev;    // (n, dof) degrees
+  const float* action;  // (n, dof)
+  float* out;           // (n, S, dof, 3)
+  int64_t n;
+  int dof, S;
+  DhConst dh;
+};
+
+__global__ __launch_bounds__(kBlock) void route_trace_kernel(const TraceArgs a) {
+  const int64_t gid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (gid >= a.n * a.S) return;
+  const int64_t env = gid / a.S;
+  const int k = (int)(gid % a.S);
+  const float inv = 1.0f / (float)(a.S - 1);
+  float X[3] = {1.f, 0.f, 0.f}, Y[3] = {0.f, 1.f, 0.f}, Z[3] = {0.f, 0.f, 1.f}, o[3] = {0.f, 0.f, 0.f};
+  float* out = a.out + gid * (int64_t)(3 * a.dof);
+  for (int j = 0; j < a.dof; ++j) {
+    const float g = a.prev[env * a.dof + j], act = a.action[env * a.dof + j];
+    // np.linspace: start + k * step, last element = stop exactly (manytor.py:182)
+    const float pose = (k == a.S - 1) ? act : __builtin_fmaf((float)k, (act - g) * inv, g);
+    float s, c;
+    sincos_deg(pose + a.dh.off_deg[j], s, c);
+    for (int q = 0; q < 3; ++q) {
+      const float nx = __builtin_fmaf(X[q], c, Y[q] * s);
+      const float tt = __builtin_fmaf(Y[q], c, -(X[q] * s));
+      o[q] = __builtin_fmaf(a.dh.a[j], nx, __builtin_fmaf(a.dh.d[j], Z[q], o[q]));
+      X[q] = nx;
+      Y[q] = __builtin_fmaf(tt, a.dh.ca[j], Z[q] * a.dh.sa[j]);
+      Z[q] = __builtin_fmaf(Z[q], a.dh.ca[j], -(tt * a.dh.sa[j]));
+      out[3 * j + q] = (j == 0) ? 0.f : o[q];   // row 0 is zeros, row j the frame after j+1 joints (manytor.py:189)
+    }
+  }
+}
+
 __global__ __launch_bounds__(kBlock) void r_theta_kernel(const float* v1, const float* v2, int64_t n, float* out) {
   const uint32_t i = blockIdx.x * kBlock + threadIdx.x;  // 32-bit lane offset: rows are addressed as uniform base + i
   if (i >= n) return;

@@ -347,6 +347,22 @@ def fk_batch(mode, angles, dh_table=REF_DH_TABLE, radians=False, device=0) -> np
     return out
 
 
+def route_trace(prev, action, dh_table=REF_DH_TABLE, substeps=25, device=0) -> np.ndarray:
+    """joints_coordinates at every sub-step pose of the routes prev[i] -> action[i] (manytor.py:182-190):
+    (n, dof) degrees in, (n, substeps, dof, 3) out."""
+    lib = L.load()
+    table = np.ascontiguousarray(np.asarray(dh_table, dtype=np.float32))
+    dof = table.shape[0]
+    p = np.ascontiguousarray(np.asarray(prev, dtype=np.float32).reshape(-1, dof))
+    a = np.ascontiguousarray(np.asarray(action, dtype=np.float32).reshape(-1, dof))
+    if p.shape != a.shape:
+        raise ValueError("prev and action must have the same shape")
+    out = np.empty((p.shape[0], int(substeps), dof, 3), dtype=np.float32)
+    L.check(lib.mt_route_trace(device, table.ctypes.data_as(C.c_void_p), dof, int(substeps), p.ctypes.data_as(C.c_void_p),
+                               a.ctypes.data_as(C.c_void_p), C.c_int64(p.shape[0]), out.ctypes.data_as(C.c_void_p)))
+    return out
+
+
 def r_theta_batch(v1, v2, device=0) -> np.ndarray:
     lib = L.load()
     a = np.ascontiguousarray(np.asarray(v1, dtype=np.float32).reshape(-1, 3))

@@ -560,6 +560,64 @@ def test_fused_rollout_with_auto_reset_equals_step_plus_reset_done(m):
     assert np.all(b.last_return()[ep > 0] == np.round(b.last_return()[ep > 0]))
 
 
+# --------------------------------------------------------------------------- sub-step trace / viewer (8f ranks 3-4)
+def test_route_trace_matches_f3_substeps(m, golden):
+    g = golden("f3_substep_trace")
+    tr = m.route_trace(g["prev"], g["action"])
+    assert tr.shape == g["jc"].shape
+    assert np.abs(tr - g["jc"]).max() <= POS_TOL
+    t7 = m.route_trace(np.zeros((3, 7)), np.full((3, 7), 30.0), dh_table=m.DH7_TABLE, substeps=5)
+    assert t7.shape == (3, 5, 7, 3) and np.all(t7[:, :, 0] == 0)
+    np.testing.assert_allclose(t7[0, 0, -1], [0, 0, 34 + 40 + 40 + 12.6 - 0.0], atol=20)   # zero pose: arm upright-ish
+
+
+def test_environment_trajectory_attribute(m, golden):
+    """manytor.py:135,190: `trajectory` = (0, 0, 51.3) seed + one end-effector row per sub-step."""
+    g = golden("f3_substep_trace")
+    env = m.Environment(1)
+    np.random.seed(0)
+    env.reset()
+    assert env.trajectory.shape == (3,)
+    env.goals = g["prev"][5]
+    env.step(list(g["action"][5]))
+    assert env.trajectory.shape == (26, 3)
+    np.testing.assert_allclose(env.trajectory[0], [0, 0, 51.3])
+    assert np.abs(env.trajectory[1:] - g["jc"][5][:, 3, :]).max() <= POS_TOL
+    env.step(list(g["action"][6]))
+    assert env.trajectory.shape == (51, 3)
+    env.reset()
+    assert env.trajectory.shape == (3,)
+
+
+def test_multienv_streams_reference_wire_format(m):
+    import json
+    import socket
+    recv = socket.socket(socket.AF_INET, socket.SOCK_DGRAM)
+    recv.setsockopt(socket.SOL_SOCKET, socket.SO_RCVBUF, 1 << 22)
+    recv.bind(("127.0.0.1", 0))
+    recv.settimeout(5.0)
+    np.random.seed(3)
+    me = m.Multienv((2, 2), 7, viewer=("127.0.0.1", recv.getsockname()[1]), view_envs=2)
+    me.reset()
+    me.step(me.action_sample())                      # not rendering yet: nothing is sent
+    me.render()
+    prev = np.array([e.goals for e in me.environment[:2]])
+    a = me.action_sample()
+    me.step(a)
+    me.render(stop_render=True)
+    got = [recv.recvfrom(2048)[0] for _ in range(1 + 2 * 25 + 1)]
+    assert json.loads(got[0]) == [2, 7, 3, [2, 2]]
+    frames = [np.array(json.loads(gm), dtype=np.float64) for gm in got[1:-1]]
+    assert all(f.size == 3 * (1 + 4 + 7 + 1) for f in frames)
+    last_env0 = [f for f in frames if int(f[0]) == 0][-1].reshape(-1, 3)
+    np.testing.assert_allclose(last_env0[1:5], me.environment[0].joints_coordinates, atol=1e-3)
+    first_env1 = [f for f in frames if int(f[0]) == 1][0].reshape(-1, 3)
+    ref = m.route_trace(prev[1:2], prev[1:2])[0, 0]
+    np.testing.assert_allclose(first_env1[1:5], ref, atol=1e-3)       # sub-step 0 = the previous pose
+    assert json.loads(got[-1])[2] == 2
+    recv.close()
+
+
 # --------------------------------------------------------------------------- boundary behaviour
 def test_errors_are_loud(m):
     eng = m.StepEngine(8, 3)
