@@ -68,6 +68,31 @@ int fail(mt_handle h, int code, const std::string& msg) {
     if (!(cond)) return fail(h, MT_ERR_INVALID_ARG, msg); \
   } while (0)
 
+// Makes `device` current for the duration of a call and restores the caller's device afterwards, so that a handle
+// living on another GPU never changes what the calling thread (e.g. torch) considers current.
+class DeviceGuard {
+ public:
+  explicit DeviceGuard(int device) {
+    if (hipGetDevice(&prev_) != hipSuccess) prev_ = -1;
+    err_ = (prev_ == device) ? hipSuccess : hipSetDevice(device);
+    changed_ = (err_ == hipSuccess && prev_ != device);
+  }
+  ~DeviceGuard() {
+    if (changed_ && prev_ >= 0) (void)hipSetDevice(prev_);
+  }
+  hipError_t error() const { return err_; }
+
+ private:
+  int prev_ = -1;
+  hipError_t err_ = hipSuccess;
+  bool changed_ = false;
+};
+
+#define MT_ON_DEVICE(h, device)                                                                      \
+  DeviceGuard mt_guard__(device);                                                                    \
+  if (mt_guard__.error() != hipSuccess)                                                              \
+  return fail(h, MT_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(mt_guard__.error()))
+
 inline dim3 grid_for(int64_t n) { return dim3((unsigned)((n + kBlock - 1) / kBlock)); }
 
 DhConst make_dh(const float* table, int dof) {
@@ -324,7 +349,8 @@ int mt_create(mt_handle* out, const mt_config* cfg) {
     if (e__ != hipSuccess) return bail(MT_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e__)); \
   } while (0)
 
-  MT_HIP_C(hipSetDevice(cfg->device));
+  DeviceGuard guard(cfg->device);
+  if (guard.error() != hipSuccess) return bail(MT_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(guard.error()));
   MT_HIP_C(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
   h->stream = h->own_stream;
   MT_HIP_C(hipEventCreate(&h->ev0));
@@ -379,7 +405,7 @@ int mt_create(mt_handle* out, const mt_config* cfg) {
 
 int mt_destroy(mt_handle h) {
   if (!h) return MT_OK;
-  (void)hipSetDevice(h->cfg.device);
+  DeviceGuard guard(h->cfg.device);
   (void)hipStreamSynchronize(h->stream);
   if (h->staging) (void)hipFree(h->staging);
   if (h->arena) (void)hipFree(h->arena);
@@ -408,7 +434,7 @@ int mt_reset(mt_handle h, const float* points, int layout, int is_device) {
   MT_REQUIRE(nullptr, h != nullptr, "handle is NULL");
   MT_REQUIRE(h, points != nullptr, "points is NULL (use mt_reset_random for device-drawn targets)");
   MT_REQUIRE(h, layout == MT_ENV_MAJOR || layout == MT_SOA, "bad layout");
-  MT_HIP(h, hipSetDevice(h->cfg.device));
+  MT_ON_DEVICE(h, h->cfg.device);
   const int rows = 3 * h->K;
   if (layout == MT_SOA) {
     const size_t bytes = (size_t)rows * h->ld * 4;
@@ -428,6 +454,7 @@ int mt_reset(mt_handle h, const float* points, int layout, int is_device) {
     int rc = check_launch(h, "env_major_to_soa");
     if (rc) return rc;
   }
+  h->args.major = 0;  // caller-supplied targets start episode 0 of every env
   MT_DISPATCH_D(h->D, launch_reset_d, h, 0);
   int rc = check_launch(h, "reset_kernel");
   if (rc) return rc;
@@ -438,7 +465,7 @@ int mt_reset(mt_handle h, const float* points, int layout, int is_device) {
 
 static int reset_random_impl(mt_handle h, uint64_t seed, uint32_t episode, int mode) {
   MT_REQUIRE(nullptr, h != nullptr, "handle is NULL");
-  MT_HIP(h, hipSetDevice(h->cfg.device));
+  MT_ON_DEVICE(h, h->cfg.device);
   h->args.seed_lo = (uint32_t)seed;
   h->args.seed_hi = (uint32_t)(seed >> 32);
   h->args.major = episode;
@@ -463,7 +490,7 @@ int mt_set_actions(mt_handle h, const void* actions, int dtype, int layout, int 
   MT_REQUIRE(h, actions != nullptr, "actions is NULL");
   MT_REQUIRE(h, layout == MT_ENV_MAJOR || layout == MT_SOA, "bad layout");
   MT_REQUIRE(h, dtype == MT_F32 || dtype == MT_F64 || dtype == MT_I32 || dtype == MT_I64, "bad action dtype");
-  MT_HIP(h, hipSetDevice(h->cfg.device));
+  MT_ON_DEVICE(h, h->cfg.device);
   const size_t es = (dtype == MT_F32 || dtype == MT_I32) ? 4 : 8;
   const int64_t cols = (layout == MT_SOA) ? h->ld : h->n;
   const size_t bytes = (size_t)h->D * cols * es;
@@ -503,7 +530,7 @@ int mt_set_actions(mt_handle h, const void* actions, int dtype, int layout, int 
 
 int mt_sample_actions(mt_handle h, uint64_t seed, uint32_t step_idx) {
   MT_REQUIRE(nullptr, h != nullptr, "handle is NULL");
-  MT_HIP(h, hipSetDevice(h->cfg.device));
+  MT_ON_DEVICE(h, h->cfg.device);
   hipLaunchKernelGGL(sample_actions_kernel, grid_for(h->n), dim3(kBlock), 0, h->stream, h->args.actions, h->n, h->ld,
                      h->D, h->args.env_base, seed, step_idx);
   return check_launch(h, "sample_actions_kernel");
@@ -513,7 +540,7 @@ int mt_sample_actions(mt_handle h, uint64_t seed, uint32_t step_idx) {
 int mt_step(mt_handle h) {
   MT_REQUIRE(nullptr, h != nullptr, "handle is NULL");
   if (!h->is_reset) return fail(h, MT_ERR_STATE, "mt_step before mt_reset / mt_reset_random");
-  MT_HIP(h, hipSetDevice(h->cfg.device));
+  MT_ON_DEVICE(h, h->cfg.device);
   launch_step(h, false);
   return check_launch(h, "step_kernel");
 }
@@ -521,7 +548,7 @@ int mt_step(mt_handle h) {
 int mt_step_random(mt_handle h, uint64_t seed, uint32_t step_idx) {
   MT_REQUIRE(nullptr, h != nullptr, "handle is NULL");
   if (!h->is_reset) return fail(h, MT_ERR_STATE, "mt_step_random before mt_reset / mt_reset_random");
-  MT_HIP(h, hipSetDevice(h->cfg.device));
+  MT_ON_DEVICE(h, h->cfg.device);
   h->args.seed_lo = (uint32_t)seed;
   h->args.seed_hi = (uint32_t)(seed >> 32);
   h->args.major = step_idx;
@@ -558,7 +585,7 @@ int mt_rollout_fused(mt_handle h, int n_steps, uint64_t seed, uint32_t step_idx0
     }
     return MT_OK;
   }
-  MT_HIP(h, hipSetDevice(h->cfg.device));
+  MT_ON_DEVICE(h, h->cfg.device);
   h->args.seed_lo = (uint32_t)seed;
   h->args.seed_hi = (uint32_t)(seed >> 32);
   RolloutArgs r{n_steps, step_idx0, auto_reset ? 1u : 0u, h->cfg.radius};
@@ -582,7 +609,7 @@ int mt_rollout_fused(mt_handle h, int n_steps, uint64_t seed, uint32_t step_idx0
 int mt_observe(mt_handle h) {
   MT_REQUIRE(nullptr, h != nullptr, "handle is NULL");
   if (!h->is_reset) return fail(h, MT_ERR_STATE, "mt_observe before reset");
-  MT_HIP(h, hipSetDevice(h->cfg.device));
+  MT_ON_DEVICE(h, h->cfg.device);
   MT_DISPATCH_D(h->D, launch_observe_d, h);
   return check_launch(h, "observe_kernel");
 }
@@ -590,7 +617,7 @@ int mt_observe(mt_handle h) {
 int mt_check_done(mt_handle h) {
   MT_REQUIRE(nullptr, h != nullptr, "handle is NULL");
   if (!h->is_reset) return fail(h, MT_ERR_STATE, "mt_check_done before reset");
-  MT_HIP(h, hipSetDevice(h->cfg.device));
+  MT_ON_DEVICE(h, h->cfg.device);
   MT_DISPATCH_D(h->D, launch_check_done_d, h);
   return check_launch(h, "check_done_kernel");
 }
@@ -622,7 +649,7 @@ int mt_get(mt_handle h, int field, void* dst, int64_t dst_bytes, int is_device) 
   const int64_t need = env_major_bytes(h, field);
   MT_REQUIRE(h, need > 0, "unknown field");
   MT_REQUIRE(h, dst_bytes == need, "dst_bytes does not match the field's env-major size");
-  MT_HIP(h, hipSetDevice(h->cfg.device));
+  MT_ON_DEVICE(h, h->cfg.device);
   const dim3 g = grid_for(h->n), b(kBlock);
   void* out = dst;
   if (!is_device) {
@@ -668,7 +695,7 @@ int mt_set(mt_handle h, int field, const void* src, int64_t src_bytes) {
              "field is not settable");
   const int64_t need = env_major_bytes(h, field);
   MT_REQUIRE(h, src_bytes == need, "src_bytes does not match the field's env-major size");
-  MT_HIP(h, hipSetDevice(h->cfg.device));
+  MT_ON_DEVICE(h, h->cfg.device);
   const dim3 g = grid_for(h->n), b(kBlock);
   const StepArgs& a = h->args;
   if (field == MT_F_TOTAL_REWARD) {
@@ -725,7 +752,7 @@ int mt_fk_batch(int device, const float* dh_table, int dof, int mode, const floa
   MT_REQUIRE(nullptr, dh_table && angles && out_mat16, "NULL argument");
   MT_REQUIRE(nullptr, dof >= 1 && dof <= MT_MAX_DOF && mode >= 0 && mode <= dof, "dof/mode out of range");
   MT_REQUIRE(nullptr, n >= 1, "n must be >= 1");
-  MT_HIP(nullptr, hipSetDevice(device));
+  MT_ON_DEVICE(nullptr, device);
   float *d_in = nullptr, *d_out = nullptr;
   MT_HIP(nullptr, hipMalloc(&d_in, (size_t)n * dof * 4));
   if (hipMalloc(&d_out, (size_t)n * 64) != hipSuccess) {
@@ -751,7 +778,7 @@ int mt_route_trace(int device, const float* dh_table, int dof, int substeps, con
   MT_REQUIRE(nullptr, dh_table && prev && action && out, "NULL argument");
   MT_REQUIRE(nullptr, dof >= 2 && dof <= MT_MAX_DOF && substeps >= 2, "dof/substeps out of range");
   MT_REQUIRE(nullptr, n >= 1 && n * substeps < ((int64_t)1 << 31), "n out of range");
-  MT_HIP(nullptr, hipSetDevice(device));
+  MT_ON_DEVICE(nullptr, device);
   const size_t in_b = (size_t)n * dof * 4, out_b = (size_t)n * substeps * dof * 3 * 4;
   char* d = nullptr;
   if (hipMalloc(&d, 2 * in_b + out_b) != hipSuccess) {
@@ -775,7 +802,7 @@ int mt_route_trace(int device, const float* dh_table, int dof, int substeps, con
 int mt_r_theta_batch(int device, const float* v1, const float* v2, int64_t n, float* out_r_theta) {
   MT_REQUIRE(nullptr, v1 && v2 && out_r_theta, "NULL argument");
   MT_REQUIRE(nullptr, n >= 1, "n must be >= 1");
-  MT_HIP(nullptr, hipSetDevice(device));
+  MT_ON_DEVICE(nullptr, device);
   float* d = nullptr;
   MT_HIP(nullptr, hipMalloc(&d, (size_t)n * 8 * 4));
   float *d1 = d, *d2 = d + 3 * n, *dout = d + 6 * n;
