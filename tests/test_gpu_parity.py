@@ -489,6 +489,38 @@ def test_full_size_properties(m, mo, n, table_name):
     np.testing.assert_array_equal(eng.alives(), alive_a)
 
 
+def test_random_action_statistics_match_the_reference(m):
+    """Distribution-level check at scale (measured on the reference with random actions, K = 7:
+    reward -1 on 80.0 % of the steps, 0 on 18.9 %, +1 on 1.1 %; nobody finishes an episode of 50 steps)."""
+    n = 65536
+    eng = m.StepEngine(n, 7)
+    eng.reset_random(123, 0)
+    counts = np.zeros(3)
+    for t in range(50):
+        eng.step_random(123, t)
+        r = eng.reward()
+        counts += [(r == -1).sum(), (r == 0).sum(), (r == 1).sum()]
+    frac = counts / counts.sum()
+    assert abs(frac[0] - 0.800) < 0.02 and abs(frac[1] - 0.189) < 0.02 and abs(frac[2] - 0.011) < 0.004, frac
+    assert eng.done().mean() < 1e-3
+    picked = 7 - eng.alives().sum(axis=1)
+    assert abs(picked.mean() - 1.74) < 0.1 and picked.max() <= 7      # oracle on the same streams (3000 envs): 1.742
+
+
+def test_full_size_fused_equals_per_step(m):
+    """1 048 576 arms x one 50-step episode: one fused launch vs 50 launches, every state bit equal."""
+    n, k, T = 1048576, 7, 50
+    a, b = m.StepEngine(n, k), m.StepEngine(n, k)
+    for e in (a, b):
+        e.reset_random(77, 0)
+    a.rollout(T, 77, 0)
+    b.rollout_fused(T, 77, 0)
+    for f in ("F_GOALS", "F_ALIVE", "F_TOTAL_REWARD", "F_POINTS", "F_OBS", "F_REWARD", "F_DONE", "F_EE", "F_DONE_BITS"):
+        np.testing.assert_array_equal(a.get(getattr(m.lib, f)), b.get(getattr(m.lib, f)), err_msg=f)
+    ret = a.total_reward()
+    assert -50 <= ret.min() and ret.max() <= 50 and abs(ret.mean() + 38.9) < 0.5      # oracle on the same streams: -38.93
+
+
 def test_reset_done_rearms_only_finished_envs(m):
     from oracle import philox_ref as px
     n, k = 4096, 1
