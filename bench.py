@@ -137,13 +137,14 @@ def main():
         while done < count:
             seg = min(count - done, L - state["step"] % L)
             if kernel_ms is not None:
-                eng.timer_start()
+                eng.lap_begin()             # HIP events on the engine's stream, no host synchronisation
             if args.fused:
                 eng.rollout_fused(seg, args.seed, state["step"])
             else:
                 eng.rollout(seg, args.seed, state["step"])
             if kernel_ms is not None:
-                kernel_ms.append((eng.timer_stop(), seg))
+                eng.lap_end()
+                kernel_ms.append(seg)
             state["step"] += seg
             done += seg
             if state["step"] % L == 0:
@@ -165,6 +166,7 @@ def main():
     run_steps(args.steps, kernel_ms)
     fence()
     elapsed = time.perf_counter() - t0
+    laps_ms, _ = eng.laps_total()                     # device time of the step launches inside the timed region
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -180,8 +182,8 @@ def main():
 
     if rank == 0:
         bpe = algorithmic_bytes_per_env_step(args.dof, args.targets)
-        launches = sum(s for _, s in kernel_ms)       # env-steps per env; = launches of step_kernel unless --fused
-        avg_kernel_s = sum(ms for ms, _ in kernel_ms) / launches / 1e3
+        launches = sum(kernel_ms)                     # env-steps per env; = launches of step_kernel unless --fused
+        avg_kernel_s = laps_ms / launches / 1e3
         achieved = bpe * n_local / avg_kernel_s / 1e9
         trig = 2 if args.hw_trig else (1 if args.direct_trig else 0)
         static = not (args.no_specialize or args.dh_in_lds)
@@ -209,6 +211,20 @@ def main():
                 "bytes_per_env_step": bpe, "avg_kernel_us": avg_kernel_s * 1e6,
             },
         }
+        if world == 1 and not args.fused and not args.ablate:
+            # informational, not the headline: the same 50-step episodes as ONE launch each
+            eng.reset_random(args.seed, 0)
+            eng.rollout_fused(L, args.seed, 0)
+            eng.sync()
+            reps = max(1, min(20, args.steps // L))
+            eng.timer_start()
+            for r in range(reps):
+                eng.rollout_fused(L, args.seed, (r + 1) * L)
+            ms = eng.timer_stop()
+            out["secondary"] = {"fused_rollout": {
+                "env_steps_per_s": n_local * L * reps / (ms / 1e3), "us_per_step": ms * 1e3 / (L * reps),
+                "steps_per_launch": L, "note": "mt_rollout_fused: state stays in registers/LDS between steps, "
+                "bit-identical results; arithmetic-bound, so the per-step byte model does not apply"}}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(table, args.targets)
         print(json.dumps(out), flush=True)

@@ -174,6 +174,12 @@ MT_API int mt_device_ptr(mt_handle h, int field, void** ptr, int64_t* rows, int6
 /* HIP-event timer on the handle's stream (wall-clock of test_multi.py:16-18, device side). */
 MT_API int mt_timer_start(mt_handle h);
 MT_API int mt_timer_stop(mt_handle h, float* elapsed_ms);
+/* Lap timer: any number of begin/end event pairs recorded on the stream WITHOUT host synchronisation;
+ * mt_timer_laps_total synchronises once, returns the summed device time of all laps and clears them.  Lets a
+ * benchmark time only its step launches inside a longer region without stalling the GPU at every lap. */
+MT_API int mt_timer_lap_begin(mt_handle h);
+MT_API int mt_timer_lap_end(mt_handle h);
+MT_API int mt_timer_laps_total(mt_handle h, float* total_ms, int* n_laps);
 
 /* Stateless kinematics helpers = the module functions of the reference.
  * mt_fk_batch: fk(mode, goals), manytor.py:35-53 -> 4x4 row-major per pose; with

@@ -11,6 +11,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <vector>
 
 #include "kernels.h"
 
@@ -34,6 +35,9 @@ struct mt_engine {
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  std::vector<hipEvent_t> lap_events;  // begin/end pairs recorded by mt_timer_lap_*; grown on demand
+  size_t laps_used = 0;                // events in use (2 per lap)
+  bool lap_open = false;
   void* arena = nullptr;
   size_t arena_bytes = 0;
   void* staging = nullptr;
@@ -411,6 +415,7 @@ int mt_destroy(mt_handle h) {
   if (h->arena) (void)hipFree(h->arena);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
+  for (hipEvent_t e : h->lap_events) (void)hipEventDestroy(e);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
   delete h;
   return MT_OK;
@@ -743,6 +748,51 @@ int mt_timer_stop(mt_handle h, float* elapsed_ms) {
   MT_HIP(h, hipEventRecord(h->ev1, h->stream));
   MT_HIP(h, hipEventSynchronize(h->ev1));
   MT_HIP(h, hipEventElapsedTime(elapsed_ms, h->ev0, h->ev1));
+  return MT_OK;
+}
+
+static int lap_record(mt_handle h) {
+  if (h->laps_used == h->lap_events.size()) {
+    hipEvent_t e = nullptr;
+    DeviceGuard guard(h->cfg.device);
+    MT_HIP(h, hipEventCreate(&e));
+    h->lap_events.push_back(e);
+  }
+  MT_HIP(h, hipEventRecord(h->lap_events[h->laps_used], h->stream));
+  ++h->laps_used;
+  return MT_OK;
+}
+
+int mt_timer_lap_begin(mt_handle h) {
+  MT_REQUIRE(nullptr, h != nullptr, "handle is NULL");
+  if (h->lap_open) return fail(h, MT_ERR_STATE, "mt_timer_lap_begin: a lap is already open");
+  int rc = lap_record(h);
+  if (rc == MT_OK) h->lap_open = true;
+  return rc;
+}
+
+int mt_timer_lap_end(mt_handle h) {
+  MT_REQUIRE(nullptr, h != nullptr, "handle is NULL");
+  if (!h->lap_open) return fail(h, MT_ERR_STATE, "mt_timer_lap_end without mt_timer_lap_begin");
+  h->lap_open = false;
+  return lap_record(h);
+}
+
+int mt_timer_laps_total(mt_handle h, float* total_ms, int* n_laps) {
+  MT_REQUIRE(nullptr, h != nullptr, "handle is NULL");
+  MT_REQUIRE(h, total_ms != nullptr, "total_ms is NULL");
+  if (h->lap_open) return fail(h, MT_ERR_STATE, "mt_timer_laps_total: a lap is still open");
+  double sum = 0.0;
+  const size_t laps = h->laps_used / 2;
+  if (laps) MT_HIP(h, hipEventSynchronize(h->lap_events[h->laps_used - 1]));
+  for (size_t i = 0; i < laps; ++i) {
+    float ms = 0.f;
+    MT_HIP(h, hipEventElapsedTime(&ms, h->lap_events[2 * i], h->lap_events[2 * i + 1]));
+    sum += ms;
+  }
+  *total_ms = (float)sum;
+  if (n_laps) *n_laps = (int)laps;
+  h->laps_used = 0;
   return MT_OK;
 }
 

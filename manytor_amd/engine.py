@@ -141,6 +141,18 @@ class StepEngine:
         self._call(self._lib.mt_timer_stop, C.byref(ms))
         return ms.value
 
+    def lap_begin(self):
+        self._call(self._lib.mt_timer_lap_begin)
+
+    def lap_end(self):
+        self._call(self._lib.mt_timer_lap_end)
+
+    def laps_total(self):
+        """(summed device milliseconds of all laps since the last call, number of laps); synchronises once."""
+        ms, n = C.c_float(0), C.c_int(0)
+        self._call(self._lib.mt_timer_laps_total, C.byref(ms), C.byref(n))
+        return ms.value, n.value
+
     # ---- reset --------------------------------------------------------------------------------
     def reset(self, points):
         """Environment.reset (manytor.py:219-253) with caller-supplied targets: (N, K, 3) host array
