@@ -284,6 +284,20 @@ def test_f5_semantics(m, golden, name):
         assert np.abs(env.joints_coordinates - g[f"{name}__jc"][t]).max() <= POS_TOL
 
 
+def test_f5_exact_threshold_case(m, golden):
+    """|delta| exactly 8.0 counts as reached (math.isclose is <=, manytor.py:162); 8.000001 does not.  Target 0 of
+    the scenario sits within one fp64 ulp of the threshold, i.e. inside the guard band: not compared."""
+    g = golden("f5_semantics_kat")
+    pts = g["threshold__points_in"]
+    env = m.Environment(len(pts))
+    np.random.seed(0)
+    env.reset()
+    env.points = pts
+    env.step([0, 0, 0, 0])
+    np.testing.assert_array_equal(env.alives[1:], g["threshold__alives"][0][1:])
+    assert list(g["threshold__alives"][0][1:]) == [False, True]
+
+
 def test_environment_piecewise_methods(m, golden):
     """get_observations / is_done / action as separate calls (manytor.py:141,155,175)."""
     g = golden("f5_semantics_kat")
