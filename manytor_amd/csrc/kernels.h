@@ -303,8 +303,19 @@ __device__ __forceinline__ float route_kinematics(const Tbl& t, int S, float inv
     float sd[D], cd[D];
     sd[0] = 0.f;
     cd[0] = 1.f;
+    // The per-sub-step increment is small (|delta| <= 15 degrees for sampled actions at S = 25): when every lane of
+    // the wave has |delta| <= 45 the quadrant reduction is skipped.  Both paths give identical bits for such
+    // angles (sincos_deg reduces with q = 0), so a lane's result does not depend on its wave-mates.
+    bool small = true;
 #pragma unroll
-    for (int j = 1; j < D; ++j) sincos_deg(st[j], sd[j], cd[j]);
+    for (int j = 1; j < D; ++j) small &= fabsf(st[j]) <= 45.0f;
+    if (__all(small)) {
+#pragma unroll
+      for (int j = 1; j < D; ++j) sincos_deg_small(st[j], sd[j], cd[j]);
+    } else {
+#pragma unroll
+      for (int j = 1; j < D; ++j) sincos_deg(st[j], sd[j], cd[j]);
+    }
     float sB[D], cB[D];
 #pragma unroll
     for (int j = 0; j < D; ++j) {

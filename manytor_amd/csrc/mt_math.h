@@ -84,18 +84,37 @@ __device__ __forceinline__ void sincos_deg_hw(float x, float& s, float& c) {
 __device__ __forceinline__ float atan2_deg_q1(float y, float x) {
   const float mx = fmaxf(x, y);
   const float mn = fminf(x, y);
-  const float q = (mx > 0.0f) ? mn * __builtin_amdgcn_rcpf(mx) : 0.0f;
+  // mx == 0 implies mn == 0, and 0 * rcp(1e-30) = 0: atan2(0, 0) = 0 without a compare/select
+  const float q = mn * __builtin_amdgcn_rcpf(fmaxf(mx, 1e-30f));
   const float w = q * q;
-  float p = -4.668773152e-03f;
-  p = __builtin_fmaf(p, w, 2.416618913e-02f);
-  p = __builtin_fmaf(p, w, -5.936710164e-02f);
-  p = __builtin_fmaf(p, w, 9.906096756e-02f);
-  p = __builtin_fmaf(p, w, -1.401658505e-01f);
-  p = __builtin_fmaf(p, w, 1.996923536e-01f);
-  p = __builtin_fmaf(p, w, -3.333196044e-01f);
-  p = __builtin_fmaf(p, w, 9.999998808e-01f);
-  const float a = p * q * 57.29577951308232f;  // degrees, in [0, 45]
+  // atan(q)/q on [0,1], already scaled to degrees (tools/gen_poly.py ATAN x 180/pi)
+  float p = -4.668773152e-03f * 57.29577951308232f;
+  p = __builtin_fmaf(p, w, 2.416618913e-02f * 57.29577951308232f);
+  p = __builtin_fmaf(p, w, -5.936710164e-02f * 57.29577951308232f);
+  p = __builtin_fmaf(p, w, 9.906096756e-02f * 57.29577951308232f);
+  p = __builtin_fmaf(p, w, -1.401658505e-01f * 57.29577951308232f);
+  p = __builtin_fmaf(p, w, 1.996923536e-01f * 57.29577951308232f);
+  p = __builtin_fmaf(p, w, -3.333196044e-01f * 57.29577951308232f);
+  p = __builtin_fmaf(p, w, 9.999998808e-01f * 57.29577951308232f);
+  const float a = p * q;  // degrees, in [0, 45]
   return (y > x) ? 90.0f - a : a;
+}
+
+// sin and cos of a SMALL angle in degrees (|x| <= 45): no quadrant reduction.  Used for the per-sub-step
+// increment delta = (action - goal) / (S - 1), |delta| <= 360 / 24 = 15 degrees for S = 25; the caller falls
+// back to sincos_deg when S is small enough for |delta| to exceed 45.
+__device__ __forceinline__ void sincos_deg_small(float f, float& s, float& c) {
+  const float z = f * f;
+  float ps = -9.621979952e-17f;
+  ps = __builtin_fmaf(ps, z, 1.349391605e-11f);
+  ps = __builtin_fmaf(ps, z, -8.860952789e-07f);
+  ps = __builtin_fmaf(ps, z, 1.745329238e-02f);
+  s = ps * f;
+  float pc = 2.099184062e-19f;
+  pc = __builtin_fmaf(pc, z, -3.925190319e-14f);
+  pc = __builtin_fmaf(pc, z, 3.866319265e-09f);
+  pc = __builtin_fmaf(pc, z, -1.523087121e-04f);
+  c = __builtin_fmaf(pc, z, 1.0f);
 }
 
 }  // namespace mt
