@@ -521,6 +521,27 @@ def test_random_action_statistics_match_the_reference(m):
     assert abs(picked.mean() - 1.74) < 0.1 and picked.max() <= 7      # oracle on the same streams (3000 envs): 1.742
 
 
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 255, 257, 16385, 1000003])
+def test_ragged_sizes_tail_handling(m, n):
+    """Sizes around wavefront / block / padding boundaries and a large prime: tail lanes exit cleanly, the last
+    done_bits word only carries live lanes, fused and per-step paths agree, neighbours of the arena are untouched."""
+    k = 3
+    a, b = m.StepEngine(n, k, pickup_tol=20.0), m.StepEngine(n, k, pickup_tol=20.0)
+    for e in (a, b):
+        e.reset_random(4, 0)
+    a.rollout(6, 4, 0)
+    b.rollout_fused(6, 4, 0)
+    for f in ("F_GOALS", "F_ALIVE", "F_TOTAL_REWARD", "F_POINTS", "F_OBS", "F_REWARD", "F_DONE", "F_EE", "F_DONE_BITS"):
+        np.testing.assert_array_equal(a.get(getattr(m.lib, f)), b.get(getattr(m.lib, f)), err_msg=f)
+    bits = a.done_bits()
+    assert bits.shape == ((n + 63) // 64,)
+    unpacked = ((bits[:, None] >> np.arange(64, dtype=np.uint64)) & np.uint64(1)).astype(bool).ravel()
+    np.testing.assert_array_equal(unpacked[:n], a.done())
+    assert not unpacked[n:].any()
+    from oracle import philox_ref as px
+    np.testing.assert_array_equal(a.goals(), px.sample_actions(4, np.arange(n, dtype=np.uint64), 5, 4))
+
+
 def test_full_size_fused_equals_per_step(m):
     """1 048 576 arms x one 50-step episode: one fused launch vs 50 launches, every state bit equal."""
     n, k, T = 1048576, 7, 50
