@@ -47,7 +47,7 @@ def init_process_group(backend=None):
     return rank, local_rank, world
 
 
-def gather_returns(local_returns, n_total: int, group=None):
+def gather_returns(local_returns, n_total: int, group=None, force_collective: bool = False):
     """All-gather the per-env episode returns of every rank into one (n_total,) tensor in global env order.
 
     `local_returns`: 1-D tensor of this rank's shard (device tensor with nccl/RCCL, CPU tensor with gloo).
@@ -55,7 +55,9 @@ def gather_returns(local_returns, n_total: int, group=None):
     4 M envs / 8 GPUs that is 2 MiB per rank); ragged shards are padded to the largest shard first."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()):
+        return local_returns.clone()
+    if dist.get_world_size(group) == 1 and not force_collective:      # force_collective: exercise RCCL on one rank
         return local_returns.clone()
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)

@@ -741,6 +741,41 @@ def test_torch_device_views_and_device_inputs(m):
     np.testing.assert_array_equal(eng.points(), pts.cpu().numpy())
 
 
+def test_rccl_single_rank_gather_of_engine_memory(m):
+    """The one collective of the multi-GPU path, on the backend the 8-GPU run uses ("nccl" = RCCL), with one rank:
+    process-group init with a device id, all_gather_into_tensor fed from a zero-copy view of the engine's arena
+    (memory RCCL never registered) and through gather_returns' staging copy."""
+    import socket
+
+    import torch
+    import torch.distributed as dist
+    from manytor_amd import distributed as D
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    n = 70000
+    eng = m.StepEngine(n, 7)
+    eng.use_torch_stream()
+    eng.reset_random(2, 0)
+    eng.rollout(5, 2, 0)
+    dist.init_process_group(backend="nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        view = eng.device_tensor(m.lib.F_TOTAL_REWARD)
+        out = torch.empty(n, dtype=torch.float32, device="cuda")
+        dist.all_gather_into_tensor(out, view)                     # straight from the arena
+        full = D.gather_returns(view, n, force_collective=True)     # the path bench.py takes
+        stats = D.reduce_return_stats(view)
+        dist.barrier()
+        torch.cuda.synchronize()
+    finally:
+        dist.destroy_process_group()
+    ref = eng.total_reward()
+    np.testing.assert_array_equal(out.cpu().numpy(), ref)
+    np.testing.assert_array_equal(full.cpu().numpy(), ref)
+    assert stats[3] == n and stats[0] == float(ref.astype(np.float64).sum())
+
+
 def test_large_multienv_returns_views_not_lists(m):
     me = m.Multienv(env_shape=(128, 64), obj_number=7, rng="device")
     obs = me.reset(returnable=True)
