@@ -78,15 +78,17 @@ typedef enum mt_dtype { MT_F32 = 0, MT_F64 = 1, MT_I32 = 2, MT_I64 = 3, MT_U8 = 
 
 typedef enum mt_layout { MT_ENV_MAJOR = 0, MT_SOA = 1 } mt_layout;
 
-/* Engine flags (mt_config.flags). Defaults (0) reproduce the reference. */
-#define MT_FLAG_TERMINATE_ON_GROUND 0x1u /* done |= ground hit (README.md:44 intent; NOT what manytor.py:170 does) */
-#define MT_FLAG_HW_TRIG 0x2u             /* v_sin/v_cos at every interior sub-step instead of the recurrence      */
-#define MT_FLAG_DH_IN_LDS 0x4u           /* stage the DH constants in LDS instead of SGPRs (measured variant;      */
-                                         /* implies the runtime-table kernel)                                      */
+/* Engine flags (mt_config.flags).  0 = the default kernels, which reproduce the reference's semantics. */
+#define MT_FLAG_TERMINATE_ON_GROUND 0x1u /* done |= ground hit (README.md:44 intent; NOT what manytor.py:170 does)  */
+/* Measured alternatives of the step kernel (profiles/r01_variants.md); same results within the fp32 tolerance. */
+#define MT_FLAG_HW_TRIG 0x2u             /* v_sin/v_cos at every interior sub-step instead of the recurrence       */
+#define MT_FLAG_DH_IN_LDS 0x4u           /* DH constants staged in LDS instead of SGPRs (implies NO_SPECIALIZE)    */
 #define MT_FLAG_DIRECT_TRIG 0x8u         /* polynomial sincos at every interior sub-step (no recurrence)           */
-#define MT_FLAG_ABLATE_LOOP 0x100u        /* DIAGNOSTIC (results wrong): skip the interior sub-steps                */
-#define MT_FLAG_ABLATE_OBS 0x200u         /* DIAGNOSTIC (results wrong): also skip the observation arithmetic       */
-#define MT_FLAG_NO_SPECIALIZE 0x10u
+#define MT_FLAG_NO_SPECIALIZE 0x10u      /* never use a compile-time DH table, even if the table matches one       */
+/* Profiling builds.  OUTPUTS ARE WRONG ON PURPOSE; never set outside bench.py --ablate. */
+#define MT_FLAG_ABLATE_LOOP 0x100u       /* skip the interior sub-steps                                            */
+#define MT_FLAG_ABLATE_OBS 0x200u        /* with ABLATE_LOOP: also skip the observation arithmetic (memory only);  */
+                                         /* alone: keep all arithmetic, drop target loads / observation stores     */
 
 /* Constructor arguments.  Replaces Environment.__init__/Multienv.__init__
  * (manytor.py:130-139, :77-82) plus the literals the reference hard-codes:

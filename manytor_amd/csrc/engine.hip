@@ -21,11 +21,6 @@ namespace {
 
 thread_local std::string g_last_error;
 
-struct Buf {
-  void* p = nullptr;
-  size_t bytes = 0;
-};
-
 }  // namespace
 
 struct mt_engine {
