@@ -227,7 +227,10 @@ void launch_joints_d(mt_handle h, float* out) {
 
 template <class Tbl>
 void launch_rollout_t(mt_handle h, const RolloutArgs& r) {
-  const size_t lds = (size_t)3 * h->K * kBlock * sizeof(float);
+  const size_t lds = (size_t)3 * h->K * kBlock * sizeof(float);  // 21.5 KB at K = 7, 96 KB at K = 32 (of 160 KB)
+  if (lds > 65536)  // above the default dynamic-LDS limit the kernel has to be told
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_kernel<Tbl>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL((rollout_kernel<Tbl>), grid_for(h->n), dim3(kBlock), lds, h->stream, h->args, r);
 }
 
@@ -571,9 +574,9 @@ int mt_rollout_fused(mt_handle h, int n_steps, uint64_t seed, uint32_t step_idx0
   MT_REQUIRE(h, n_steps >= 0, "n_steps must be >= 0");
   if (!h->is_reset) return fail(h, MT_ERR_STATE, "mt_rollout_fused before mt_reset / mt_reset_random");
   if (n_steps == 0) return MT_OK;
-  // The fused kernel keeps the targets of a block in LDS (12*K*256 bytes) and implements the default
-  // trigonometry only; otherwise run the same thing as a sequence of launches.
-  const bool fusable = h->trig == 0 && !h->lds_table && (size_t)3 * h->K * kBlock * sizeof(float) <= 65536;
+  // The fused kernel implements the default trigonometry only; the measured alternatives run the same thing as a
+  // sequence of launches.
+  const bool fusable = h->trig == 0 && !h->lds_table;
   if (!fusable) {
     for (int s = 0; s < n_steps; ++s) {
       int rc = mt_step_random(h, seed, step_idx0 + (uint32_t)s);
