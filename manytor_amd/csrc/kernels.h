@@ -249,17 +249,14 @@ struct TableMaker<RtTable<D>> {
   static __device__ __forceinline__ RtTable<D> make(const DhConst& c) { return RtTable<D>{c}; }
 };
 
-// Environment.action_sample for one env (manytor.py:215-217): D integer degrees from Philox blocks.
+// Environment.action_sample for one env (manytor.py:215-217): D integer degrees from one Philox block.
 template <int D>
 __device__ __forceinline__ void draw_action(uint64_t seed, uint64_t env_id, uint32_t step_idx, float (&act)[D]) {
+  static_assert(D <= 8, "one Philox block yields at most 8 joint angles");
+  const u32x4 w = stream_block(seed, env_id, kTagAction, step_idx, 0u);
+  const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
-  for (int b = 0; b < (D + 3) / 4; ++b) {
-    const u32x4 w = stream_block(seed, env_id, kTagAction, step_idx, (uint32_t)b);
-    const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-      if (4 * b + q < D) act[4 * b + q] = action_from_word(ws[q]);
-  }
+  for (int j = 0; j < D; ++j) act[j] = (j < 4) ? action_from_word(ws[j]) : action_from_word_digit1(ws[j - 4]);
 }
 
 // The kinematic part of Environment.action (manytor.py:178-192) for one env: S poses on the straight line in
@@ -475,12 +472,10 @@ __global__ __launch_bounds__(kBlock) void sample_actions_kernel(float* actions, 
                                                                 int64_t env_base, uint64_t seed, uint32_t step_idx) {
   const uint32_t i = blockIdx.x * kBlock + threadIdx.x;  // 32-bit lane offset: rows are addressed as uniform base + i
   if (i >= n) return;
-  for (int b = 0; b < (D + 3) / 4; ++b) {
-    const u32x4 w = stream_block(seed, (uint64_t)(env_base + i), kTagAction, step_idx, (uint32_t)b);
-    const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
-    for (int q = 0; q < 4; ++q)
-      if (4 * b + q < D) (actions + (int64_t)(4 * b + q) * ld)[i] = action_from_word(ws[q]);
-  }
+  const u32x4 w = stream_block(seed, (uint64_t)(env_base + i), kTagAction, step_idx, 0u);
+  const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
+  for (int j = 0; j < D; ++j)
+    (actions + (int64_t)j * ld)[i] = (j < 4) ? action_from_word(ws[j]) : action_from_word_digit1(ws[j - 4]);
 }
 
 // ---------------------------------------------------------------------------

@@ -43,8 +43,15 @@ __host__ __device__ __forceinline__ u32x4 stream_block(uint64_t seed, uint64_t e
   return philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
 }
 
-// integer degrees uniform in [-180, 180)  (manytor.py:216)
+// Integer degrees uniform in [-180, 180) (manytor.py:216) from a 32-bit word read as a fixed-point fraction u:
+// digit 0 = floor(360 u), and the leftover fraction 360 u - floor(360 u) (the low half of the 64-bit product) is
+// again uniform, so digit 1 = floor(360 * fraction) is a second, independent draw from the same word (joint
+// probabilities deviate from 1/360^2 by at most 360^2 / 2^32 = 3e-5 relative).  One Philox block therefore
+// covers up to 8 joints: joint j < 4 is digit 0 of word j, joint j >= 4 is digit 1 of word j - 4.
 __host__ __device__ __forceinline__ float action_from_word(uint32_t w) { return (float)mulhi32(w, 360u) - 180.0f; }
+__host__ __device__ __forceinline__ float action_from_word_digit1(uint32_t w) {
+  return (float)mulhi32(w * 360u, 360u) - 180.0f;
+}
 
 // u in [0,1) with 24 bits
 __host__ __device__ __forceinline__ float u01(uint32_t w) { return (float)(w >> 8) * 5.9604644775390625e-08f; }

@@ -11,8 +11,10 @@ bit-for-bit.
 
 Stream definitions (key = (seed_lo, seed_hi)):
   counter = (env_lo, (env_hi & 0x00FFFFFF) | tag << 24, major, minor)
-  actions : tag 1, major = step index, minor = block (joints 4*block..4*block+3)
-            angle_j = float(mulhi32(u_j, 360)) - 180      -> integer degrees in [-180, 180)
+  actions : tag 1, major = step index, minor = 0; one block serves up to 8 joints:
+            joint j < 4 : float(mulhi32(w_j, 360)) - 180                    (digit 0 of word j)
+            joint j >= 4: float(mulhi32(lo32(w_{j-4} * 360), 360)) - 180    (digit 1 of word j-4)
+            -> integer degrees in [-180, 180)
   targets : tag 2, major = episode index, minor = draw index (0,1,2,...)
             u01(w) = (w >> 8) * 2^-24
             x = 2R*u01(w0) - R ; y = 2R*u01(w1) - R ; z = R*u01(w2)   (fp32, one rounding per op)
@@ -59,16 +61,16 @@ def _ctr(env_ids, tag):
 
 
 def sample_actions(seed, env_ids, step_idx, dof):
-    """(N, dof) float32 integer-valued degrees in [-180, 180)."""
+    """(N, dof) float32 integer-valued degrees in [-180, 180).  One Philox block per env and step: joint j < 4 is
+    digit 0 of word j (floor(360 u)), joint j >= 4 is digit 1 of word j - 4 (floor(360 * frac(360 u)))."""
     lo, hi = _ctr(env_ids, TAG_ACTION)
     out = np.empty((lo.shape[0], dof), dtype=np.float32)
-    for blk in range((dof + 3) // 4):
-        w = philox4x32_10(lo, hi, np.uint64(step_idx & 0xFFFFFFFF), np.uint64(blk), seed & 0xFFFFFFFF, seed >> 32)
-        for j in range(4):
-            col = 4 * blk + j
-            if col < dof:
-                v = (w[j].astype(np.uint64) * np.uint64(360)) >> np.uint64(32)
-                out[:, col] = v.astype(np.float32) - np.float32(180.0)
+    w = philox4x32_10(lo, hi, np.uint64(step_idx & 0xFFFFFFFF), np.uint64(0), seed & 0xFFFFFFFF, seed >> 32)
+    for col in range(dof):
+        prod = w[col % 4].astype(np.uint64) * np.uint64(360)
+        if col >= 4:
+            prod = (prod & MASK) * np.uint64(360)
+        out[:, col] = (prod >> np.uint64(32)).astype(np.float32) - np.float32(180.0)
     return out
 
 
