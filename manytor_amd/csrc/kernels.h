@@ -323,6 +323,7 @@ __device__ __forceinline__ float route_kinematics(const Tbl& t, int S, float inv
     cB[0] = 1.f;
     const int nf = (S - 1) / 2;   // forward poses k = 1..nf
     const int nb = S - 2 - nf;    // backward poses k = S-2..nf+1   (nb = nf or nf-1)
+#pragma unroll 2
     for (int it = 1; it <= nf; ++it) {
 #pragma unroll
       for (int j = 1; j < D; ++j) {  // rotate by +delta
