@@ -21,6 +21,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--envs", type=int, default=1 << 20)
 ap.add_argument("--steps", type=int, default=200)
 ap.add_argument("--targets", type=int, default=7)
+ap.add_argument("--graph", action="store_true", help="capture policy + env step into one HIP graph and replay it")
 args = ap.parse_args()
 
 eng = m.StepEngine(args.envs, args.targets)
@@ -39,15 +40,32 @@ def policy():
     torch.tanh(w @ obs, out=act).mul_(179.0)
 
 
-for _ in range(5):
+def one_step():
     policy()
     eng.step()
+
+
+for _ in range(5):
+    one_step()
 torch.cuda.synchronize()
+if args.graph:
+    # The engine launches on torch's stream and mt_step calls nothing capture-hostile (no malloc, no sync),
+    # so torch's stream capture records the policy kernels and the env step into one HIP graph.
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        eng.use_torch_stream()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            one_step()
+    torch.cuda.synchronize()
+    run = g.replay
+else:
+    run = one_step
 t0 = time.perf_counter()
 for _ in range(args.steps):
-    policy()
-    eng.step()
+    run()
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 print(f"{args.envs} arms x {args.steps} steps with a torch policy in the loop: {args.envs * args.steps / dt:.3e} env-steps/s "
-      f"({dt / args.steps * 1e6:.1f} us per step incl. the policy GEMM); mean return {ret.mean().item():.2f}")
+      f"({dt / args.steps * 1e6:.1f} us per step incl. the policy GEMM{', one HIP graph per step' if args.graph else ''}); "
+      f"mean return {ret.mean().item():.2f}")

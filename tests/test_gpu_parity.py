@@ -776,6 +776,38 @@ def test_rccl_single_rank_gather_of_engine_memory(m):
     assert stats[3] == n and stats[0] == float(ref.astype(np.float64).sum())
 
 
+def test_step_is_capturable_in_a_hip_graph(m):
+    """mt_step launches on the caller's stream and does nothing capture-hostile (no allocation, no sync), so a
+    torch stream capture records `write actions -> env step` as one HIP graph; replays equal eager stepping."""
+    import torch
+    n, k = 20000, 7
+    eager, graphed = m.StepEngine(n, k), m.StepEngine(n, k)
+    for e in (eager, graphed):
+        e.use_torch_stream()
+        e.reset_random(6, 0)
+    acts = torch.randint(-180, 180, (6, 4, n), device="cuda").to(torch.float32)
+    for t in range(6):
+        eager.device_tensor(m.lib.F_ACTIONS).copy_(acts[t])
+        eager.step()
+    static_in = torch.zeros((4, n), device="cuda")
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        graphed.use_torch_stream()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            graphed.device_tensor(m.lib.F_ACTIONS).copy_(static_in)
+            graphed.step()
+    torch.cuda.synchronize()
+    graphed.reset_random(6, 0)            # the capture pass itself does not execute; start from the same state anyway
+    for t in range(6):
+        static_in.copy_(acts[t])
+        graph.replay()
+    torch.cuda.synchronize()
+    for f in ("F_GOALS", "F_ALIVE", "F_TOTAL_REWARD", "F_OBS", "F_REWARD", "F_DONE", "F_EE"):
+        np.testing.assert_array_equal(eager.get(getattr(m.lib, f)), graphed.get(getattr(m.lib, f)), err_msg=f)
+
+
 def test_large_multienv_returns_views_not_lists(m):
     me = m.Multienv(env_shape=(128, 64), obj_number=7, rng="device")
     obs = me.reset(returnable=True)
