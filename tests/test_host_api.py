@@ -72,6 +72,20 @@ def test_no_gpu_means_loud_failure_not_fallback(lib):
         m.fk(4, [0, 0, 0, 0])
 
 
+def test_missing_extension_is_a_loud_import_error(lib, monkeypatch):
+    """No .so, no product: nothing falls back to numpy."""
+    from manytor_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", os.path.join(ROOT, "manytor_amd", "no_such_library.so"))
+    with pytest.raises(ImportError, match="no CPU fallback"):
+        _lib.load()
+    import manytor_amd as m
+    with pytest.raises(ImportError):
+        m.StepEngine(4, 2)
+    with pytest.raises(ImportError):
+        m.fk(4, [0, 0, 0, 0])
+
+
 def test_invalid_config_is_rejected_before_touching_a_device(lib):
     from manytor_amd import _lib
     cfg = _lib.MtConfig()
@@ -80,6 +94,11 @@ def test_invalid_config_is_rejected_before_touching_a_device(lib):
     assert lib.mt_create(ctypes.byref(h), ctypes.byref(cfg)) == _lib.MT_ERR_INVALID_ARG
     assert b"struct_size" in lib.mt_last_error(None)
     cfg.struct_size = ctypes.sizeof(_lib.MtConfig)
+    cfg.n_envs, cfg.dof, cfg.n_targets, cfg.substeps = 0, 4, 7, 25           # empty batch
+    assert lib.mt_create(ctypes.byref(h), ctypes.byref(cfg)) == _lib.MT_ERR_INVALID_ARG
+    assert b"n_envs" in lib.mt_last_error(None)
+    cfg.n_envs = 1 << 31                                                     # beyond the 32-bit row offsets
+    assert lib.mt_create(ctypes.byref(h), ctypes.byref(cfg)) == _lib.MT_ERR_INVALID_ARG
     cfg.n_envs, cfg.dof, cfg.n_targets, cfg.substeps = 16, 9, 7, 25
     assert lib.mt_create(ctypes.byref(h), ctypes.byref(cfg)) == _lib.MT_ERR_INVALID_ARG
     assert b"dof" in lib.mt_last_error(None)
