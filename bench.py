@@ -225,6 +225,23 @@ def main():
                 "env_steps_per_s": n_local * L * reps / (ms / 1e3), "us_per_step": ms * 1e3 / (L * reps),
                 "steps_per_launch": L, "note": "mt_rollout_fused: state stays in registers/LDS between steps, "
                 "bit-identical results; arithmetic-bound, so the per-step byte model does not apply"}}
+        if world == 1 and not args.fused and not args.ablate and not args.no_cpu_baseline:
+            # informational: BASELINE.json's other single-GPU configurations, same kernel path, short runs
+            out["secondary"]["other_configs"] = {}
+            for label, n2, tbl, rad in (("configs[1]: 65536 arms, 4-DoF", 65536, m.REF_DH_TABLE, 51.3),
+                                        ("configs[4]: 1048576 arms, 7-DoF table", 1048576, m.DH7_TABLE, 92.6)):
+                e2 = m.StepEngine(n2, args.targets, dh_table=tbl, radius=rad, device=dev)
+                e2.reset_random(args.seed, 0)
+                e2.rollout(200, args.seed, 0)
+                e2.sync()
+                e2.timer_start()
+                e2.rollout(600, args.seed, 200)
+                us = e2.timer_stop() * 1e3 / 600
+                b2 = algorithmic_bytes_per_env_step(len(tbl), args.targets)
+                out["secondary"]["other_configs"][label] = {
+                    "us_per_step": us, "env_steps_per_s": n2 / (us * 1e-6), "bytes_per_env_step": b2,
+                    "frac_of_hbm_peak": b2 * n2 / (us * 1e-6) / 1e9 / HBM_PEAK_GBS}
+                e2.close()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(table, args.targets)
         print(json.dumps(out), flush=True)
