@@ -53,10 +53,23 @@ def cpu_baseline(dof_table, k, budget_s=12.0, n=65536):
         ora.step(acts[1 + steps])
         steps += 1
     dt = time.perf_counter() - t0
+    # the reference's own shape of the computation: one env at a time, three FK chains per sub-step (manytor.py:188)
+    envs = [mo.ScalarEnv(k, table=table) for _ in range(16)]
+    pts = px.sample_targets(0x5EED, ids[:16], 0, k, 51.3)
+    for e, p in zip(envs, pts):
+        e.reset(points=p)
+    t1 = time.perf_counter()
+    for t in range(12):
+        for j, e in enumerate(envs):
+            e.step(acts[t][j])
+    dt_scalar = time.perf_counter() - t1
     return {
         "value": n * steps / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
         "sample": f"{n} envs x {steps} steps, vectorised numpy fp64 (oracle/manytor_oracle.py BatchOracle), "
                   f"{dt:.1f} s on 1 of {os.cpu_count()} host cores",
+        "scalar_faithful_value": 16 * 12 / dt_scalar,
+        "scalar_faithful_sample": "16 envs x 12 steps, per-env Python loop with the reference's 75 FK chains per step "
+                                  "(oracle ScalarEnv), 1 core; multi-process figure: profiles/r01_cpu_baselines_gpu_box.json",
     }
 
 
