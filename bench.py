@@ -73,6 +73,22 @@ def cpu_baseline(dof_table, k, budget_s=12.0, n=65536):
     }
 
 
+def measured_copy_bandwidth(torch, nbytes=1 << 30, reps=20):
+    """Device-to-device copy rate on this GPU (read + write bytes per second): the practical HBM ceiling that
+    SURVEY.md 8(d) asks to quote next to the 8 TB/s spec figure."""
+    src = torch.empty(nbytes // 4, dtype=torch.float32, device="cuda").normal_()
+    dst = torch.empty_like(src)
+    for _ in range(3):
+        dst.copy_(src)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    for _ in range(reps):
+        dst.copy_(src)
+    ev1.record()
+    torch.cuda.synchronize()
+    return 2.0 * nbytes * reps / (ev0.elapsed_time(ev1) * 1e-3) / 1e9
+
+
 def load_traffic(workload_key):
     """HBM bytes per step launch from the committed PMC run (profiles/), or None."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
@@ -224,6 +240,10 @@ def main():
                 "bytes_per_env_step": bpe, "avg_kernel_us": avg_kernel_s * 1e6,
             },
         }
+        if world == 1:
+            copy_gbs = measured_copy_bandwidth(torch)
+            out["roofline"]["measured_copy_gbs"] = copy_gbs
+            out["roofline"]["frac_of_measured_copy"] = achieved / copy_gbs
         if world == 1 and not args.fused and not args.ablate:
             # informational, not the headline: the same 50-step episodes as ONE launch each
             eng.reset_random(args.seed, 0)

@@ -199,6 +199,14 @@ def test_f2_single_env_trace_through_environment_class(m, golden):
     assert not diverged or t > 10
 
 
+def test_survey_kat_observation_after_seeded_reset(m):
+    """SURVEY.md 8(a) A4, measured on the reference: np.random.seed(0); Environment(3).reset(returnable=True)."""
+    np.random.seed(0)
+    obs = m.Environment(3).reset(returnable=True)
+    ref = [28.958179, 12.780675, 51.425159, 16.382115, 30.451181, 33.686785, 41.183154, 21.779136, 51.503084]
+    np.testing.assert_allclose(obs, ref, atol=2e-4)
+
+
 def test_f3_substep_ground_flag(m, mo, golden):
     g = golden("f3_substep_trace")
     n = len(g["prev"])
