@@ -145,6 +145,10 @@ MT_API int mt_sample_actions(mt_handle h, uint64_t seed, uint32_t step_idx);
 /* Environment.step() = get_observations() side effect + action() + return
  * accumulation + is_done(), manytor.py:255-260, :175-213, for all envs, one launch. */
 MT_API int mt_step(mt_handle h);
+/* One host round trip of Multienv.step (manytor.py:115-122): (N, D) host actions in, obs2 (N, 3K) f32, reward (N,)
+ * i32 and done (N,) u8 out, through one page-locked staging buffer and ONE stream synchronisation (instead of the
+ * four that mt_set_actions + mt_step + 3 x mt_get cost).  For small batches driven from host code. */
+MT_API int mt_step_host(mt_handle h, const void* actions, int dtype, float* obs, int32_t* reward, uint8_t* done);
 /* The same with the action drawn in-kernel (results bit-identical to mt_sample_actions followed by
  * mt_step).  The drawn action is not stored in MT_F_ACTIONS: it is the new MT_F_GOALS (goals = action after a
  * step, manytor.py:184), which saves 4*D bytes of traffic per env. */

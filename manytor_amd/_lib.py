@@ -82,6 +82,7 @@ PROTOTYPES = {
     "mt_set_actions": (C.c_int, [_HANDLE, C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "mt_sample_actions": (C.c_int, [_HANDLE, C.c_uint64, C.c_uint32]),
     "mt_step": (C.c_int, [_HANDLE]),
+    "mt_step_host": (C.c_int, [_HANDLE, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mt_step_random": (C.c_int, [_HANDLE, C.c_uint64, C.c_uint32]),
     "mt_rollout": (C.c_int, [_HANDLE, C.c_int, C.c_uint64, C.c_uint32]),
     "mt_rollout_fused": (C.c_int, [_HANDLE, C.c_int, C.c_uint64, C.c_uint32, C.c_int]),

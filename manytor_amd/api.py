@@ -222,6 +222,13 @@ class Multienv:
         """manytor.py:115-122 -> (obs2_list, reward_list, done_list)."""
         streaming = self.rendering and self._viewer is not None
         prev = self._cached(L.F_GOALS).copy() if streaming else None
+        host_action = action is not DEVICE_ACTIONS and not (hasattr(action, "is_cuda") and action.is_cuda)
+        if self._materialize and host_action:
+            obs, rew, done = self._engine.step_host(action)      # one round trip, one synchronisation
+            self._step_idx += 1
+            if streaming:
+                self._stream_frames(prev)
+            return [row.astype(np.float64) for row in obs], [int(r) for r in rew], [bool(d) for d in done]
         if action is DEVICE_ACTIONS:
             self._engine.step()
         else:
@@ -358,12 +365,11 @@ class Environment:
         """manytor.py:255-260 -> (obs2, reward, done)."""
         prev = self._engine.goals() if (self._keep_trajectory or (self.rendering and self._viewer)) else None
         act = np.asarray(action, dtype=np.float64).reshape(1, -1)
-        self._engine.step(act)
+        obs, rew, done = self._engine.step_host(act)
         self._step_idx += 1
         if prev is not None:
             self._after_route(prev, act)
-        e = self._engine
-        return e.obs()[0].astype(np.float64), int(e.reward()[0]), bool(e.done()[0])
+        return obs[0].astype(np.float64), int(rew[0]), bool(done[0])
 
     def render(self, stop_render=False, multienv=False):
         """manytor.py:262-283.  Flag always; init / stop datagrams if a ViewerLink was given (`viewer=(host, port)`).

@@ -37,6 +37,8 @@ struct mt_engine {
   size_t arena_bytes = 0;
   void* staging = nullptr;
   size_t staging_bytes = 0;
+  void* pinned = nullptr;  // page-locked host buffer of mt_step_host
+  size_t pinned_bytes = 0;
   StepArgs args{};
   bool is_reset = false;
   int trig = 0;          // 0 recurrence, 1 polynomial sincos per sub-step, 2 hardware trig per sub-step
@@ -410,6 +412,7 @@ int mt_destroy(mt_handle h) {
   DeviceGuard guard(h->cfg.device);
   (void)hipStreamSynchronize(h->stream);
   if (h->staging) (void)hipFree(h->staging);
+  if (h->pinned) (void)hipHostFree(h->pinned);
   if (h->arena) (void)hipFree(h->arena);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -546,6 +549,57 @@ int mt_step(mt_handle h) {
   MT_ON_DEVICE(h, h->cfg.device);
   launch_step(h, false);
   return check_launch(h, "step_kernel");
+}
+
+int mt_step_host(mt_handle h, const void* actions, int dtype, float* obs, int32_t* reward, uint8_t* done) {
+  MT_REQUIRE(nullptr, h != nullptr, "handle is NULL");
+  MT_REQUIRE(h, actions && obs && reward && done, "NULL argument");
+  MT_REQUIRE(h, dtype == MT_F32 || dtype == MT_F64 || dtype == MT_I32 || dtype == MT_I64, "bad action dtype");
+  if (!h->is_reset) return fail(h, MT_ERR_STATE, "mt_step_host before mt_reset / mt_reset_random");
+  MT_ON_DEVICE(h, h->cfg.device);
+  const size_t n = (size_t)h->n, es = (dtype == MT_F32 || dtype == MT_I32) ? 4 : 8;
+  const size_t in_b = n * h->D * es, obs_b = n * 3 * h->K * 4, rew_b = n * 4, done_b = n;
+  const size_t out_b = obs_b + rew_b + done_b, total = align_up(in_b, 256) + out_b;
+  if (h->pinned_bytes < total) {
+    if (h->pinned) {
+      MT_HIP(h, hipStreamSynchronize(h->stream));
+      (void)hipHostFree(h->pinned);
+      h->pinned = nullptr;
+      h->pinned_bytes = 0;
+    }
+    if (hipHostMalloc(&h->pinned, total, hipHostMallocDefault) != hipSuccess) {
+      (void)hipGetLastError();
+      return fail(h, MT_ERR_ALLOC, "hipHostMalloc failed");
+    }
+    h->pinned_bytes = total;
+  }
+  int rc = ensure_staging(h, total);
+  if (rc) return rc;
+  char* hp = (char*)h->pinned;
+  char* dp = (char*)h->staging;
+  char* hp_out = hp + align_up(in_b, 256);
+  char* dp_out = dp + align_up(in_b, 256);
+  std::memcpy(hp, actions, in_b);
+  MT_HIP(h, hipMemcpyAsync(dp, hp, in_b, hipMemcpyHostToDevice, h->stream));
+  const dim3 g = grid_for(h->n), b(kBlock);
+  switch (dtype) {
+    case MT_F32: hipLaunchKernelGGL((env_major_to_soa<float>), g, b, 0, h->stream, (const float*)dp, h->D, h->n, h->args.actions, h->ld); break;
+    case MT_F64: hipLaunchKernelGGL((env_major_to_soa<double>), g, b, 0, h->stream, (const double*)dp, h->D, h->n, h->args.actions, h->ld); break;
+    case MT_I32: hipLaunchKernelGGL((env_major_to_soa<int32_t>), g, b, 0, h->stream, (const int32_t*)dp, h->D, h->n, h->args.actions, h->ld); break;
+    default: hipLaunchKernelGGL((env_major_to_soa<int64_t>), g, b, 0, h->stream, (const int64_t*)dp, h->D, h->n, h->args.actions, h->ld); break;
+  }
+  launch_step(h, false);
+  hipLaunchKernelGGL((soa_to_env_major<float>), g, b, 0, h->stream, h->args.obs, h->ld, 3 * h->K, h->n, (float*)dp_out);
+  rc = check_launch(h, "mt_step_host");
+  if (rc) return rc;
+  MT_HIP(h, hipMemcpyAsync(dp_out + obs_b, h->args.reward, rew_b, hipMemcpyDeviceToDevice, h->stream));
+  MT_HIP(h, hipMemcpyAsync(dp_out + obs_b + rew_b, h->args.done, done_b, hipMemcpyDeviceToDevice, h->stream));
+  MT_HIP(h, hipMemcpyAsync(hp_out, dp_out, out_b, hipMemcpyDeviceToHost, h->stream));
+  MT_HIP(h, hipStreamSynchronize(h->stream));  // the only host wait of the call
+  std::memcpy(obs, hp_out, obs_b);
+  std::memcpy(reward, hp_out + obs_b, rew_b);
+  std::memcpy(done, hp_out + obs_b + rew_b, done_b);
+  return MT_OK;
 }
 
 int mt_step_random(mt_handle h, uint64_t seed, uint32_t step_idx) {

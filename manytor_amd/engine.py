@@ -232,6 +232,24 @@ class StepEngine:
         self._call(self._lib.mt_step)
         self.version += 1
 
+    def step_host(self, actions):
+        """One host round trip: (N, D) host actions in -> (obs2 (N, 3K) f32, reward (N,) i32, done (N,) bool) out,
+        with a single synchronisation.  The small-batch path of the drop-in classes."""
+        n, d = self.n_envs, self.dof
+        a = np.asarray(actions)
+        if a.dtype not in _ACTION_DT:
+            a = a.astype(np.float64)
+        if a.size != n * d:
+            raise ValueError(f"actions must have {n}x{d} elements, got shape {a.shape}")
+        a = np.ascontiguousarray(a.reshape(n, d))
+        obs = np.empty((n, 3 * self.obj_number), dtype=np.float32)
+        rew = np.empty(n, dtype=np.int32)
+        done = np.empty(n, dtype=np.uint8)
+        self._call(self._lib.mt_step_host, a.ctypes.data_as(C.c_void_p), _ACTION_DT[a.dtype],
+                   obs.ctypes.data_as(C.c_void_p), rew.ctypes.data_as(C.c_void_p), done.ctypes.data_as(C.c_void_p))
+        self.version += 1
+        return obs, rew, done.astype(bool)
+
     def step_random(self, seed=0x5EED, step_idx=0):
         self._call(self._lib.mt_step_random, C.c_uint64(seed), C.c_uint32(step_idx))
         self.version += 1

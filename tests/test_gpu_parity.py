@@ -710,6 +710,25 @@ def test_errors_are_loud(m):
         eng.step(np.zeros((8, 4)))
 
 
+def test_step_host_equals_set_step_get(m):
+    n, k = 777, 5
+    rng = np.random.RandomState(3)
+    a, b = m.StepEngine(n, k), m.StepEngine(n, k)
+    pts = rng.uniform(-30, 30, size=(n, k, 3)).astype(np.float32)
+    a.reset(pts)
+    b.reset(pts)
+    for cast in (np.int64, np.float32, np.float64, np.int32):
+        act = rng.randint(-180, 180, size=(n, 4)).astype(cast)
+        a.step(act)
+        obs, rew, done = b.step_host(act)
+        np.testing.assert_array_equal(obs, a.obs())
+        np.testing.assert_array_equal(rew, a.reward())
+        np.testing.assert_array_equal(done, a.done())
+        np.testing.assert_array_equal(b.goals(), a.goals())
+    with pytest.raises(ValueError):
+        b.step_host(np.zeros((n - 1, 4)))
+
+
 def test_action_dtypes_and_layouts(m):
     n = 300
     rng = np.random.RandomState(0)
