@@ -380,14 +380,6 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const StepArgs a) {
   const uint32_t i = blockIdx.x * kBlock + threadIdx.x;  // 32-bit lane offset: rows are addressed as uniform base + i
   if (i >= a.n) return;
   const int64_t ld = a.ld;
-#ifdef MT_STAGGER_PRIO
-  switch ((blockIdx.x >> MT_STAGGER_SHIFT) & 3u) {
-    case 1: __builtin_amdgcn_s_setprio(1); break;
-    case 2: __builtin_amdgcn_s_setprio(2); break;
-    case 3: __builtin_amdgcn_s_setprio(3); break;
-    default: break;
-  }
-#endif
 
   float g[D], act[D];
 #pragma unroll
