@@ -36,24 +36,43 @@ def algorithmic_bytes_per_env_step(dof, k):
     return 12 * dof + 24 * k + 33
 
 
-def cpu_baseline(dof_table, k, budget_s=12.0, n=65536):
-    """The numpy port of the step path (oracle/, parity-checked against the reference's fixtures), timed on
-    this box's host cores on a bounded sample of the same workload.  Baseline, not the target."""
+def cpu_baseline(dof_table, k, budget_s=12.0, n=65536, threads=16):
+    """The CPU port of the step path (oracle/: parity-checked against the reference's fixtures), timed on this box's
+    host cores on a bounded sample of the same workload.  Headline figure: the C restatement with OpenMP on the
+    box's CPU share; beside it the vectorised-numpy and the scalar (reference-shaped) Python figures on one core.
+    Baseline, not the target."""
+    from oracle import c_oracle
     from oracle import manytor_oracle as mo
     from oracle import philox_ref as px
     table = np.asarray(dof_table)
+    dof = table.shape[0]
+    threads = max(1, min(threads, os.cpu_count() or 1))
+    # (a) C + OpenMP
+    nc = 1 << 20
+    idc = np.arange(nc, dtype=np.uint64)
+    cora = c_oracle.COracle(nc, k, table=table, threads=threads)
+    cora.reset(px.sample_targets(0x5EED, idc, 0, k, 51.3).astype(np.float64))
+    cacts = [px.sample_actions(0x5EED, idc, t, dof).astype(np.float64) for t in range(4)]
+    cora.step(cacts[0])
+    t0 = time.perf_counter()
+    csteps = 0
+    while csteps < 1 or (time.perf_counter() - t0 < budget_s and csteps < 200):
+        cora.step(cacts[csteps % 4])
+        csteps += 1
+    dt_c = time.perf_counter() - t0
+    # (b) vectorised numpy, one core
     ids = np.arange(n, dtype=np.uint64)
     ora = mo.BatchOracle(n, k, table=table)
     ora.reset(px.sample_targets(0x5EED, ids, 0, k, 51.3).astype(np.float64))
-    acts = [px.sample_actions(0x5EED, ids, t, table.shape[0]).astype(np.float64) for t in range(64)]
-    ora.step(acts[0])                                   # warm-up
+    acts = [px.sample_actions(0x5EED, ids, t, dof).astype(np.float64) for t in range(16)]
+    ora.step(acts[0])
     t0 = time.perf_counter()
     steps = 0
-    while steps < 2 or (time.perf_counter() - t0 < budget_s and steps < 63):
+    while steps < 2 or (time.perf_counter() - t0 < budget_s / 3 and steps < 15):
         ora.step(acts[1 + steps])
         steps += 1
     dt = time.perf_counter() - t0
-    # the reference's own shape of the computation: one env at a time, three FK chains per sub-step (manytor.py:188)
+    # (c) the reference's own shape of the computation: one env at a time, three FK chains per sub-step (manytor.py:188)
     envs = [mo.ScalarEnv(k, table=table) for _ in range(16)]
     pts = px.sample_targets(0x5EED, ids[:16], 0, k, 51.3)
     for e, p in zip(envs, pts):
@@ -64,12 +83,14 @@ def cpu_baseline(dof_table, k, budget_s=12.0, n=65536):
             e.step(acts[t][j])
     dt_scalar = time.perf_counter() - t1
     return {
-        "value": n * steps / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
-        "sample": f"{n} envs x {steps} steps, vectorised numpy fp64 (oracle/manytor_oracle.py BatchOracle), "
-                  f"{dt:.1f} s on 1 of {os.cpu_count()} host cores",
-        "scalar_faithful_value": 16 * 12 / dt_scalar,
+        "value": nc * csteps / dt_c, "unit": "env-steps/s", "cores": threads, "kind": "port",
+        "sample": f"{nc} envs x {csteps} steps, C restatement of the reference with OpenMP (oracle/manytor_oracle.c), "
+                  f"{dt_c:.1f} s on {threads} of {os.cpu_count()} host cores",
+        "numpy_vectorised_value_1core": n * steps / dt,
+        "numpy_vectorised_sample": f"{n} envs x {steps} steps, oracle BatchOracle fp64, {dt:.1f} s",
+        "scalar_faithful_value_1core": 16 * 12 / dt_scalar,
         "scalar_faithful_sample": "16 envs x 12 steps, per-env Python loop with the reference's 75 FK chains per step "
-                                  "(oracle ScalarEnv), 1 core; multi-process figure: profiles/r01_cpu_baselines_gpu_box.json",
+                                  "(oracle ScalarEnv)",
     }
 
 
