@@ -15,7 +15,7 @@
  *     the last error is available through mt_last_error().
  *   - plain pointers and sizes only; no C++ / torch types.
  *   - a handle owns one device, one HIP stream (replaceable with
- *     mt_set_stream) and all of its device buffers.  A handle is not
+ *     mt_set_stream / mt_use_own_stream) and all of its device buffers.  A handle is not
  *     re-entrant; different handles may be used from different threads.
  *   - launches are asynchronous on the handle's stream; mt_sync() or any
  *     host-destination mt_get() synchronises.
@@ -40,9 +40,11 @@ extern "C" {
 #define MT_API
 #endif
 
-#define MT_VERSION 100          /* major*10000 + minor*100 + patch */
+#define MT_VERSION 200          /* major*10000 + minor*100 + patch */
 #define MT_MAX_DOF 8
 #define MT_MAX_TARGETS 32
+#define MT_MAX_RETURN_RING 64
+#define MT_UNIQUE_ID_BYTES 128     /* = NCCL_UNIQUE_ID_BYTES of RCCL */
 
 typedef struct mt_engine* mt_handle;
 
@@ -64,14 +66,20 @@ typedef enum mt_field {
   MT_F_ALIVE = 3,         /* u8   (N, K) via mt_get; device: u32 bitmask per env (bit p = target p alive)    */
   MT_F_OBS = 4,           /* f32  (N, 3K)               rows: 3K           obs2 of the last step / observe   */
   MT_F_REWARD = 5,        /* i32  (N,)                                      reward of the last step           */
-  MT_F_DONE = 6,          /* u8   (N,)                                      done of the last step             */
+  MT_F_DONE = 6,          /* u8   (N,)   done of the last step: 0 running, 1 finished (mt_reset_done will re-arm it),  */
+                          /*             2 finished and already re-armed inside mt_rollout_fused(auto_reset)          */
   MT_F_DONE_BITS = 7,     /* u64  (ceil(N/64),) one wavefront ballot per 64 envs, bit l = env 64*w + l       */
   MT_F_EE = 8,            /* f32  (N, 3)                rows: 3            end effector = joints_coordinates[-1] */
   MT_F_TOTAL_REWARD = 9,  /* f32  (N,)                                      manytor.py:138 `total_reward`     */
   MT_F_JOINTS = 10,       /* f32  (N, D, 3) computed on demand from goals (manytor.py:188-189); mt_get only  */
   MT_F_EPISODES = 11,     /* u32  (N,)   episode index of each env: set by a reset, +1 per auto re-arm          */
   MT_F_LAST_RETURN = 12,  /* f32  (N,)   total_reward the env had when it was last reset / re-armed             */
-  MT_F_COUNT = 13
+  MT_F_RETURN_RING = 13,  /* f32  (N, R) rows: R = mt_config.return_ring.  The return of the c-th episode an env finished */
+                          /*             since the last full reset (re-armed by mt_reset_done or in-kernel) is in slot   */
+                          /*             c % R; c = MT_F_EPISODES - (episode of the last full reset)                     */
+  MT_F_TRACE = 14,        /* f32  (N, S, 3) rows: 3S.  End effector at each of the S sub-step poses of the last step     */
+                          /*             (the rows manytor.py:190 appends to `trajectory`); needs MT_FLAG_TRACE          */
+  MT_F_COUNT = 15
 } mt_field;
 
 typedef enum mt_dtype { MT_F32 = 0, MT_F64 = 1, MT_I32 = 2, MT_I64 = 3, MT_U8 = 4, MT_U32 = 5, MT_U64 = 6 } mt_dtype;
@@ -85,6 +93,8 @@ typedef enum mt_layout { MT_ENV_MAJOR = 0, MT_SOA = 1 } mt_layout;
 #define MT_FLAG_DH_IN_LDS 0x4u           /* DH constants staged in LDS instead of SGPRs (implies NO_SPECIALIZE)    */
 #define MT_FLAG_DIRECT_TRIG 0x8u         /* polynomial sincos at every interior sub-step (no recurrence)           */
 #define MT_FLAG_NO_SPECIALIZE 0x10u      /* never use a compile-time DH table, even if the table matches one       */
+#define MT_FLAG_TRACE 0x20u              /* keep MT_F_TRACE: every step also writes the end effector of each       */
+                                         /* sub-step pose (300 B/env-step at S = 25; off by default, manytor.py:190) */
 /* Profiling builds.  OUTPUTS ARE WRONG ON PURPOSE; never set outside bench.py --ablate. */
 #define MT_FLAG_ABLATE_LOOP 0x100u       /* skip the interior sub-steps                                            */
 #define MT_FLAG_ABLATE_OBS 0x200u        /* with ABLATE_LOOP: also skip the observation arithmetic (memory only);  */
@@ -106,6 +116,8 @@ typedef struct mt_config {
   float pickup_tol;             /* reference 8.0                                                 */
   float radius;                 /* target hemisphere radius, reference 51.3                      */
   float dh_table[MT_MAX_DOF * 4]; /* rows (a, alpha_rad, d, theta_offset_rad), manytor.py:42-48 */
+  int32_t return_ring;          /* slots of MT_F_RETURN_RING per env, 0..MT_MAX_RETURN_RING (0 = none) */
+  int32_t reserved;             /* must be 0                                                     */
 } mt_config;
 
 MT_API int mt_version(void);
@@ -118,8 +130,13 @@ MT_API int mt_device_count(int* count);
 /* Environment()/Multienv() constructors, manytor.py:130-139 / :77-82. */
 MT_API int mt_create(mt_handle* out, const mt_config* cfg);
 MT_API int mt_destroy(mt_handle h);
-/* Run on a caller-owned hipStream_t (e.g. torch's current stream); NULL restores the handle's own. */
+/* Run on a caller-owned hipStream_t (e.g. torch's current stream), so that the handle's launches are ordered with
+ * the caller's own work on that stream.  NULL means what it means to HIP: the legacy default stream (which is what
+ * torch's default stream is).  mt_use_own_stream goes back to the handle's private non-blocking stream, which is
+ * NOT ordered against any other stream: readers of the device buffers must then mt_sync() first.  Both calls
+ * drain the stream the handle was on. */
 MT_API int mt_set_stream(mt_handle h, void* hip_stream);
+MT_API int mt_use_own_stream(mt_handle h);
 MT_API int mt_sync(mt_handle h);
 
 /* Environment.reset(), manytor.py:219-253, for all envs.
@@ -130,10 +147,15 @@ MT_API int mt_sync(mt_handle h);
  * seed / global env id / episode), same law as manytor.py:229-239. */
 MT_API int mt_reset(mt_handle h, const float* points, int layout, int is_device);
 MT_API int mt_reset_random(mt_handle h, uint64_t seed, uint32_t episode);
-/* Re-arm only the envs whose done byte is set: their return goes to MT_F_LAST_RETURN, their episode index
- * (MT_F_EPISODES) advances by one and keys the new targets (device RNG), pose and return are zeroed.  Not in
- * the reference (the caller resets everything, test_multi.py:34); SURVEY.md 8(f) rank 1. */
+/* Re-arm only the envs whose done byte is 1: their return goes to MT_F_LAST_RETURN and into MT_F_RETURN_RING, their
+ * episode index (MT_F_EPISODES) advances by one and keys the new targets (device RNG), pose and return are zeroed.
+ * Envs with done == 2 were already re-armed inside mt_rollout_fused: only their flag is cleared.  Not in the
+ * reference (the caller resets everything, test_multi.py:34; reset on done is caller-driven, test_single.py:20-21,32);
+ * SURVEY.md 8(f) rank 1. */
 MT_API int mt_reset_done(mt_handle h, uint64_t seed);
+/* `multienv.environment[i].reset()` (manytor.py:82 + :219-253): reset ONE env of the batch.  `points` = K x 3 host
+ * floats, or NULL to draw them on the device (Philox keyed by seed / global env id / `episode`). */
+MT_API int mt_env_reset(mt_handle h, int64_t env, const float* points, uint64_t seed, uint32_t episode);
 
 /* Stage the action of the next mt_step: (N, D) env-major or (D, ld) SoA, degrees,
  * any of f32/f64/i32/i64 (Environment.action_sample returns np.int64, manytor.py:216). */
@@ -149,6 +171,13 @@ MT_API int mt_step(mt_handle h);
  * i32 and done (N,) u8 out, through one page-locked staging buffer and ONE stream synchronisation (instead of the
  * four that mt_set_actions + mt_step + 3 x mt_get cost).  For small batches driven from host code. */
 MT_API int mt_step_host(mt_handle h, const void* actions, int dtype, float* obs, int32_t* reward, uint8_t* done);
+/* `multienv.environment[i].step(action)` (manytor.py:82,118 + :255-260): step ONE env of the batch with a host action of
+ * D degrees; the other envs are untouched.  obs (3K f32), reward, done are written to host memory; synchronises. */
+MT_API int mt_env_step(mt_handle h, int64_t env, const float* action, float* obs, int32_t* reward, uint8_t* done);
+/* Number of (env, step) pairs so far whose staged action was not a finite angle of magnitude <= 32768 degrees (NaN,
+ * +-inf from a diverging policy ...).  Such an env holds its pose for that step instead of poisoning its state.
+ * Synchronises.  The reference has no such check (numpy would propagate the NaN into goals, manytor.py:184). */
+MT_API int mt_bad_action_count(mt_handle h, uint64_t* count);
 /* The same with the action drawn in-kernel (results bit-identical to mt_sample_actions followed by
  * mt_step).  The drawn action is not stored in MT_F_ACTIONS: it is the new MT_F_GOALS (goals = action after a
  * step, manytor.py:184), which saves 4*D bytes of traffic per env. */
@@ -158,7 +187,9 @@ MT_API int mt_step_random(mt_handle h, uint64_t seed, uint32_t step_idx);
 MT_API int mt_rollout(mt_handle h, int n_steps, uint64_t seed, uint32_t step_idx0);
 /* The same n_steps steps in ONE launch: joint angles, alive mask and return stay in registers and the targets
  * in LDS between steps, so a step only writes its outputs (obs, reward, done, end effector; MT_F_* hold the last
- * step's).  auto_reset != 0 re-arms an env in the step it finishes, exactly like mt_reset_done after every step.
+ * step's).  auto_reset != 0 re-arms an env in the step it finishes, exactly like mt_reset_done after every step:
+ * every finished return lands in MT_F_RETURN_RING, and an env that finished in the LAST step keeps done == 2
+ * (finished, already re-armed) so that a following mt_reset_done does not reset it twice.
  * State after the call is bit-identical to the launch-per-step sequence. */
 MT_API int mt_rollout_fused(mt_handle h, int n_steps, uint64_t seed, uint32_t step_idx0, int auto_reset);
 
@@ -176,6 +207,24 @@ MT_API int mt_get(mt_handle h, int field, void* dst, int64_t dst_bytes, int is_d
 MT_API int mt_set(mt_handle h, int field, const void* src, int64_t src_bytes);
 /* Raw resident buffer: pointer to row 0, number of rows, row stride in elements and element dtype. */
 MT_API int mt_device_ptr(mt_handle h, int field, void** ptr, int64_t* rows, int64_t* ld, int* dtype);
+
+/* ---- multi-GPU: the one exchange of the path ---------------------------------------------------
+ * Envs share nothing, so stepping needs no collective.  What is exchanged is what test_multi.py:32 prints: the
+ * per-env return, all-gathered over the ranks (one process per GPU) with RCCL over xGMI, straight out of the
+ * arena on the handle's stream -- no staging copy, no host round trip.  librccl.so is dlopen'ed on first use, so the
+ * library loads and runs on a box without RCCL.
+ *   rank 0: mt_comm_unique_id(id)  ->  ship the 128 bytes to the other ranks by any means (the Python host uses the
+ *   torch.distributed store)  ->  every rank: mt_comm_init(h, id, rank, world)  [collective, ncclCommInitRank]. */
+MT_API int mt_comm_unique_id(void* id_out /* MT_UNIQUE_ID_BYTES */);
+MT_API int mt_comm_init(mt_handle h, const void* unique_id, int rank, int world_size);
+MT_API int mt_comm_destroy(mt_handle h);
+/* All-gather row `row` of a single-precision field (MT_F_TOTAL_REWARD, MT_F_LAST_RETURN: row 0; MT_F_RETURN_RING: a
+ * slot) of every rank into dst (device memory, global env order, dst_elems = total number of envs over all ranks;
+ * shards may differ in size).  Asynchronous on the handle's stream.  Without mt_comm_init (one GPU) it is a
+ * device-to-device copy. */
+MT_API int mt_gather_returns(mt_handle h, int field, int row, float* dst, int64_t dst_elems);
+/* Total number of envs over all ranks of the communicator (n_envs without one). */
+MT_API int mt_comm_total_envs(mt_handle h, int64_t* total);
 
 /* HIP-event timer on the handle's stream (wall-clock of test_multi.py:16-18, device side). */
 MT_API int mt_timer_start(mt_handle h);

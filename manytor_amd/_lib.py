@@ -13,6 +13,8 @@ LIB_PATH = os.path.join(PKG_DIR, "libmanytor_hip.so")
 
 MT_MAX_DOF = 8
 MT_MAX_TARGETS = 32
+MT_MAX_RETURN_RING = 64
+MT_UNIQUE_ID_BYTES = 128
 
 # mt_status
 MT_OK = 0
@@ -25,7 +27,7 @@ MT_ERR_UNSUPPORTED = -6
 
 # mt_field
 (F_ACTIONS, F_GOALS, F_POINTS, F_ALIVE, F_OBS, F_REWARD, F_DONE, F_DONE_BITS, F_EE, F_TOTAL_REWARD, F_JOINTS,
- F_EPISODES, F_LAST_RETURN) = range(13)
+ F_EPISODES, F_LAST_RETURN, F_RETURN_RING, F_TRACE) = range(15)
 # mt_dtype
 DT_F32, DT_F64, DT_I32, DT_I64, DT_U8, DT_U32, DT_U64 = range(7)
 # mt_layout
@@ -36,6 +38,7 @@ FLAG_HW_TRIG = 0x2
 FLAG_DH_IN_LDS = 0x4
 FLAG_DIRECT_TRIG = 0x8
 FLAG_NO_SPECIALIZE = 0x10
+FLAG_TRACE = 0x20
 FLAG_ABLATE_LOOP = 0x100
 FLAG_ABLATE_OBS = 0x200
 
@@ -61,6 +64,8 @@ class MtConfig(C.Structure):
         ("pickup_tol", C.c_float),
         ("radius", C.c_float),
         ("dh_table", C.c_float * (MT_MAX_DOF * 4)),
+        ("return_ring", C.c_int32),
+        ("reserved", C.c_int32),
     ]
 
 
@@ -75,14 +80,18 @@ PROTOTYPES = {
     "mt_create": (C.c_int, [C.POINTER(_HANDLE), C.POINTER(MtConfig)]),
     "mt_destroy": (C.c_int, [_HANDLE]),
     "mt_set_stream": (C.c_int, [_HANDLE, C.c_void_p]),
+    "mt_use_own_stream": (C.c_int, [_HANDLE]),
     "mt_sync": (C.c_int, [_HANDLE]),
     "mt_reset": (C.c_int, [_HANDLE, C.c_void_p, C.c_int, C.c_int]),
     "mt_reset_random": (C.c_int, [_HANDLE, C.c_uint64, C.c_uint32]),
     "mt_reset_done": (C.c_int, [_HANDLE, C.c_uint64]),
+    "mt_env_reset": (C.c_int, [_HANDLE, C.c_int64, C.c_void_p, C.c_uint64, C.c_uint32]),
     "mt_set_actions": (C.c_int, [_HANDLE, C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "mt_sample_actions": (C.c_int, [_HANDLE, C.c_uint64, C.c_uint32]),
     "mt_step": (C.c_int, [_HANDLE]),
     "mt_step_host": (C.c_int, [_HANDLE, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mt_env_step": (C.c_int, [_HANDLE, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mt_bad_action_count": (C.c_int, [_HANDLE, C.POINTER(C.c_uint64)]),
     "mt_step_random": (C.c_int, [_HANDLE, C.c_uint64, C.c_uint32]),
     "mt_rollout": (C.c_int, [_HANDLE, C.c_int, C.c_uint64, C.c_uint32]),
     "mt_rollout_fused": (C.c_int, [_HANDLE, C.c_int, C.c_uint64, C.c_uint32, C.c_int]),
@@ -92,6 +101,11 @@ PROTOTYPES = {
     "mt_set": (C.c_int, [_HANDLE, C.c_int, C.c_void_p, C.c_int64]),
     "mt_device_ptr": (C.c_int, [_HANDLE, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_int64),
                                 C.POINTER(C.c_int)]),
+    "mt_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "mt_comm_init": (C.c_int, [_HANDLE, C.c_void_p, C.c_int, C.c_int]),
+    "mt_comm_destroy": (C.c_int, [_HANDLE]),
+    "mt_gather_returns": (C.c_int, [_HANDLE, C.c_int, C.c_int, C.c_void_p, C.c_int64]),
+    "mt_comm_total_envs": (C.c_int, [_HANDLE, C.POINTER(C.c_int64)]),
     "mt_timer_start": (C.c_int, [_HANDLE]),
     "mt_timer_stop": (C.c_int, [_HANDLE, C.POINTER(C.c_float)]),
     "mt_timer_lap_begin": (C.c_int, [_HANDLE]),
@@ -105,6 +119,30 @@ PROTOTYPES = {
 _lib = None
 
 
+def _share_torch_hip_runtime():
+    """A torch-ROCm wheel bundles its own libamdhip64.so (soname libamdhip64.so.7) and librccl.so.  Two HIP runtimes
+    in one process do not share streams, events or allocations, so if torch is installed its copy is loaded FIRST
+    (without importing torch): this library's `libamdhip64.so.7` dependency then resolves to it, whatever the import
+    order, and comm.hip is pointed at the RCCL that sits on the same runtime.  Without torch the system ROCm is used."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+    hip = os.path.join(libdir, "libamdhip64.so")
+    if os.path.exists(hip):
+        try:
+            C.CDLL(hip, mode=C.RTLD_GLOBAL)
+        except OSError:
+            return
+        rccl = os.path.join(libdir, "librccl.so")
+        if os.path.exists(rccl):
+            os.environ.setdefault("MT_RCCL_LIB", rccl)
+
+
 def load():
     """Load (once) and return the ctypes library.  Raises if it is missing."""
     global _lib
@@ -115,6 +153,7 @@ def load():
             f"{LIB_PATH} not found: the HIP extension has not been built. "
             "Run `python -m manytor_amd.build` (needs hipcc); this package has no CPU fallback."
         )
+    _share_torch_hip_runtime()
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)     # AttributeError if the .so does not export what the header declares

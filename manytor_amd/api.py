@@ -86,27 +86,71 @@ class BatchView:
 
 
 class _EnvView:
-    """``multienv.environment[i]``: attribute access to one env of the batch (manytor.py:131-139)."""
+    """``multienv.environment[i]``: one env of the batch with the reference ``Environment``'s attributes and methods
+    (the reference's list holds real Environment objects, manytor.py:82, so callers may step / reset one of them).
+    Whole-batch calls on the Multienv are the fast path; these touch a single env (mt_env_step / mt_env_reset) and
+    leave the others alone."""
 
     def __init__(self, owner, index):
         self._o, self.id = owner, index
 
+    def _write(self, field, value, dtype):
+        full = self._o._engine.get(field)
+        full[self.id] = np.asarray(value, dtype=dtype).reshape(full[self.id].shape)
+        self._o._engine.set(field, full)
+
     obj_number = property(lambda s: s._o.obj_number)
     rendering = property(lambda s: s._o.rendering)
-    goals = property(lambda s: s._o._cached(L.F_GOALS)[s.id].astype(np.float64))
-    alives = property(lambda s: s._o._cached(L.F_ALIVE)[s.id].astype(bool))
-    points = property(lambda s: s._o._cached(L.F_POINTS)[s.id].astype(np.float64))
+    goals = property(lambda s: s._o._cached(L.F_GOALS)[s.id].astype(np.float64),
+                     lambda s, v: s._write(L.F_GOALS, v, np.float32))
+    alives = property(lambda s: s._o._cached(L.F_ALIVE)[s.id].astype(bool),
+                      lambda s, v: s._write(L.F_ALIVE, v, np.uint8))
+    points = property(lambda s: s._o._cached(L.F_POINTS)[s.id].astype(np.float64),
+                      lambda s, v: s._write(L.F_POINTS, v, np.float32))
     joints_coordinates = property(lambda s: s._o._cached(L.F_JOINTS)[s.id].astype(np.float64))
-    total_reward = property(lambda s: float(s._o._cached(L.F_TOTAL_REWARD)[s.id]))
+    total_reward = property(lambda s: float(s._o._cached(L.F_TOTAL_REWARD)[s.id]),
+                            lambda s, v: s._write(L.F_TOTAL_REWARD, v, np.float32))
 
     def get_observations(self):
+        """manytor.py:141-153 (recomputed for the batch; row `id` returned)."""
         self._o._engine.observe()
         return self._o._cached(L.F_OBS)[self.id].astype(np.float64)
 
     get_obs = get_observations
 
     def is_done(self):
-        return not self.alives.any()
+        """manytor.py:155-173."""
+        self._o._engine.check_done()
+        return bool(self._o._cached(L.F_DONE)[self.id])
+
+    def action_sample(self):
+        """manytor.py:215-217."""
+        o = self._o
+        if o.rng == "numpy":
+            return list(_rng.draw_actions(1, o._engine.dof)[0])
+        return [np.int64(v) for v in np.random.randint(-180, 180, size=o._engine.dof)]
+
+    def step(self, action):
+        """manytor.py:255-260 for this env only -> (obs2, reward, done)."""
+        obs, rew, done = self._o._engine.env_step(self.id, action)
+        return obs.astype(np.float64), rew, done
+
+    def action(self, action, obs=None):
+        """manytor.py:175-213 -> (reward, obs2); does not accumulate into total_reward (that is step's job, :258)."""
+        before = self.total_reward
+        obs2, rew, _ = self.step(action)
+        self.total_reward = before
+        return rew, obs2
+
+    def reset(self, returnable=False):
+        """manytor.py:219-253 for this env only."""
+        o = self._o
+        if o.rng == "numpy":
+            o._engine.env_reset(self.id, _rng.draw_targets(1, o.obj_number, o.radius)[0])
+        else:
+            o._engine.env_reset(self.id, None, seed=o.seed, episode=o._episode)
+        if returnable:
+            return self.get_observations()
 
 
 class _EnvList:
@@ -272,8 +316,11 @@ class Environment:
         self._dh_table = dh_table
         self._substeps = substeps
         self._fresh = True
-        # manytor.py:135: end-effector trace, one row per sub-step, seeded with (0, 0, 51.3)
-        self.trajectory = np.array([0.0, 0.0, 51.3])
+        # manytor.py:135: end-effector trace, one row per sub-step, seeded with (0, 0, 51.3).  Kept lazily: a step only
+        # notes its (previous pose, action) pair; the rows are computed -- one mt_route_trace call for all pending
+        # steps -- when `trajectory` is read.
+        self._traj = np.array([0.0, 0.0, 51.3])
+        self._traj_pending = []
         self.id = index
         self.obj_number = obj_number
         self.rendering = False
@@ -288,10 +335,14 @@ class Environment:
         # the reference constructor leaves points/joints empty until reset() (manytor.py:136-137);
         # arm the device state at the zero pose so attribute reads are defined
         self._engine.reset(np.zeros((1, obj_number, 3), dtype=np.float32))
+        self._pose = np.zeros((1, self._engine.dof), dtype=np.float32)   # host mirror of `goals` (= the last action)
 
     # state attributes (manytor.py:131-139); reads are D2H copies, writes are H2D
-    goals = property(lambda s: s._engine.goals()[0].astype(np.float64),
-                     lambda s, v: s._engine.set(L.F_GOALS, np.asarray(v, dtype=np.float32).reshape(1, -1)))
+    def _set_goals(self, v):
+        self._pose = np.asarray(v, dtype=np.float32).reshape(1, -1).copy()
+        self._engine.set(L.F_GOALS, self._pose)
+
+    goals = property(lambda s: s._engine.goals()[0].astype(np.float64), _set_goals)
     alives = property(lambda s: s._engine.alives()[0],
                       lambda s, v: s._engine.set(L.F_ALIVE, np.asarray(v, dtype=np.uint8).reshape(1, -1)))
     points = property(lambda s: s._engine.points()[0].astype(np.float64),
@@ -299,6 +350,22 @@ class Environment:
     total_reward = property(lambda s: float(s._engine.total_reward()[0]),
                             lambda s, v: s._engine.set(L.F_TOTAL_REWARD, np.asarray([v], dtype=np.float32)))
     joints_coordinates = property(lambda s: s._engine.joints_coordinates()[0].astype(np.float64))
+
+    @property
+    def trajectory(self):
+        """manytor.py:135,190: (0, 0, 51.3) + the end effector at every sub-step since the last reset."""
+        if self._traj_pending:
+            prev = np.concatenate([p for p, _ in self._traj_pending])
+            act = np.concatenate([a for _, a in self._traj_pending])
+            self._traj_pending = []
+            trace = route_trace(prev, act, dh_table=self._dh_table, substeps=self._substeps, device=self._engine.device)
+            self._traj = np.vstack((self._traj, trace[:, :, -1, :].reshape(-1, 3).astype(np.float64)))
+        return self._traj
+
+    @trajectory.setter
+    def trajectory(self, value):
+        self._traj_pending = []
+        self._traj = np.asarray(value, dtype=np.float64)
 
     @property
     def engine(self) -> StepEngine:
@@ -317,15 +384,14 @@ class Environment:
         return bool(self._engine.done()[0])
 
     def _after_route(self, prev, action):
-        """Host-side bookkeeping the reference does per sub-step (manytor.py:190, :194-202): trajectory rows and
-        viewer frames, from one route_trace call after the step has run."""
+        """Host-side bookkeeping the reference does per sub-step (manytor.py:190, :194-202): the trajectory rows (noted
+        here, computed when read) and, while rendering, the viewer frames of the route just taken."""
         streaming = self.rendering and self._viewer is not None
-        if not (self._keep_trajectory or streaming):
-            return
-        trace = route_trace(prev, action, dh_table=self._dh_table, substeps=self._substeps, device=self._engine.device)
         if self._keep_trajectory:
-            self.trajectory = np.vstack((self.trajectory, trace[0, :, -1, :].astype(np.float64)))
+            self._traj_pending.append((np.asarray(prev, dtype=np.float32).reshape(1, -1),
+                                       np.asarray(action, dtype=np.float32).reshape(1, -1)))
         if streaming:
+            trace = route_trace(prev, action, dh_table=self._dh_table, substeps=self._substeps, device=self._engine.device)
             self._viewer.frames([self.id], trace, self._engine.points(), first=self._fresh)
             self._fresh = False
 
@@ -333,10 +399,11 @@ class Environment:
         """manytor.py:175-213 -> (reward, obs2).  Like the reference it does not add to total_reward;
         the fused step kernel does, so the increment is taken back out."""
         before = self._engine.total_reward()
-        prev = self._engine.goals()
+        prev = self._pose
         act = np.asarray(action, dtype=np.float64).reshape(1, -1)
         self._engine.step(act)
         self._engine.set(L.F_TOTAL_REWARD, before)
+        self._pose = act.astype(np.float32)               # goals = action after a step (manytor.py:184)
         self._after_route(prev, act)
         return int(self._engine.reward()[0]), self._engine.obs()[0].astype(np.float64)
 
@@ -354,7 +421,8 @@ class Environment:
         else:
             self._engine.reset_random(self.seed, self._episode)
         self._episode += 1
-        self.trajectory = np.array([0.0, 0.0, 51.3])      # manytor.py:223
+        self._pose = np.zeros_like(self._pose)
+        self.trajectory = np.array([0.0, 0.0, 51.3])      # manytor.py:223 (drops pending rows)
         self._fresh = True
         if self.rendering and self._viewer is not None:
             self._viewer.clear()                           # manytor.py:246-249
@@ -363,12 +431,12 @@ class Environment:
 
     def step(self, action):
         """manytor.py:255-260 -> (obs2, reward, done)."""
-        prev = self._engine.goals() if (self._keep_trajectory or (self.rendering and self._viewer)) else None
+        prev = self._pose
         act = np.asarray(action, dtype=np.float64).reshape(1, -1)
         obs, rew, done = self._engine.step_host(act)
         self._step_idx += 1
-        if prev is not None:
-            self._after_route(prev, act)
+        self._pose = act.astype(np.float32)               # goals = action after a step (manytor.py:184)
+        self._after_route(prev, act)
         return obs[0].astype(np.float64), int(rew[0]), bool(done[0])
 
     def render(self, stop_render=False, multienv=False):

@@ -14,8 +14,8 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 INCLUDE = os.path.join(os.path.dirname(PKG_DIR), "include")
 LIB_PATH = os.path.join(PKG_DIR, "libmanytor_hip.so")
-SOURCES = ["engine.hip"]
-DEPS = ["engine.hip", "kernels.h", "mt_math.h", "philox.h"]
+SOURCES = ["engine.hip", "comm.hip"]
+DEPS = ["engine.hip", "comm.hip", "engine_internal.h", "step_args.h", "kernels.h", "mt_math.h", "philox.h"]
 
 
 def _hipcc() -> str:

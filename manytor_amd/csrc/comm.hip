@@ -1,0 +1,250 @@
+// The one exchange of the multi-GPU path: all-gather of per-env returns over RCCL / xGMI.
+//
+// The reference has no distributed layer (its "multi-env" is a serial Python loop, manytor.py:115-122); what is
+// gathered here is what test_multi.py:32 prints per env.  One process per GPU; the communicator belongs to the
+// handle and runs on the handle's stream, reading the arena row directly (no staging for equal shards).
+// librccl.so is resolved at run time with dlopen, so the library itself links only libamdhip64.
+#include <dlfcn.h>
+
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "engine_internal.h"
+
+using namespace mt;
+
+namespace {
+
+// The handful of RCCL entry points used, with the types of <rccl/rccl.h> (ncclResult_t and the enums are ints;
+// ncclUniqueId is a 128-byte struct passed BY VALUE to ncclCommInitRank).
+struct UniqueId {
+  char internal[MT_UNIQUE_ID_BYTES];
+};
+using Comm = void*;
+constexpr int kNcclSuccess = 0;
+constexpr int kNcclInt64 = 4;    // ncclInt64
+constexpr int kNcclFloat32 = 7;  // ncclFloat32
+
+struct Rccl {
+  void* lib = nullptr;
+  int (*GetUniqueId)(UniqueId*) = nullptr;
+  int (*CommInitRank)(Comm*, int, UniqueId, int) = nullptr;
+  int (*CommDestroy)(Comm) = nullptr;
+  int (*AllGather)(const void*, void*, size_t, int, Comm, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+  std::string where, error;
+};
+
+std::mutex g_rccl_mu;
+Rccl g_rccl;
+
+template <typename F>
+bool sym(void* lib, const char* name, F& fn) {
+  fn = reinterpret_cast<F>(dlsym(lib, name));
+  return fn != nullptr;
+}
+
+// Resolution order: $MT_RCCL_LIB (the Python host points it at the copy that shares torch's HIP runtime), a copy the
+// process has already loaded, then the system one.
+Rccl* rccl() {
+  std::lock_guard<std::mutex> lock(g_rccl_mu);
+  if (g_rccl.lib) return &g_rccl;
+  std::vector<std::pair<std::string, int>> tries;
+  if (const char* env = std::getenv("MT_RCCL_LIB"))
+    if (*env) tries.push_back({env, RTLD_NOW | RTLD_LOCAL});
+  tries.push_back({"librccl.so.1", RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD});
+  tries.push_back({"librccl.so.1", RTLD_NOW | RTLD_LOCAL});
+  tries.push_back({"librccl.so", RTLD_NOW | RTLD_LOCAL});
+  std::string errs;
+  for (auto& t : tries) {
+    void* lib = dlopen(t.first.c_str(), t.second);
+    if (!lib) {
+      const char* e = dlerror();
+      errs += t.first + ": " + (e ? e : "not loaded") + "; ";
+      continue;
+    }
+    Rccl r;
+    if (sym(lib, "ncclGetUniqueId", r.GetUniqueId) && sym(lib, "ncclCommInitRank", r.CommInitRank) &&
+        sym(lib, "ncclCommDestroy", r.CommDestroy) && sym(lib, "ncclAllGather", r.AllGather) &&
+        sym(lib, "ncclGetErrorString", r.GetErrorString)) {
+      r.lib = lib;
+      r.where = t.first;
+      g_rccl = r;
+      return &g_rccl;
+    }
+    errs += t.first + ": missing nccl* symbols; ";
+    dlclose(lib);
+  }
+  g_rccl.error = errs;
+  return nullptr;
+}
+
+}  // namespace
+
+struct mt_comm {
+  Comm comm = nullptr;
+  int rank = 0, world = 1;
+  std::vector<int64_t> counts;  // envs of every rank
+  int64_t total = 0, cmax = 0;
+  bool equal = true;
+  float* stage = nullptr;       // ragged shards only: [world + 1][cmax] (slot `world` = padded send buffer)
+};
+
+#define MT_NCCL(h, r, call)                                                                              \
+  do {                                                                                                   \
+    int e__ = (call);                                                                                    \
+    if (e__ != kNcclSuccess)                                                                             \
+      return fail(h, MT_ERR_HIP, std::string(#call) + ": " + ((r)->GetErrorString ? (r)->GetErrorString(e__) : "?")); \
+  } while (0)
+
+void mt_comm_release(mt_handle h) {
+  if (!h || !h->comm) return;
+  mt_comm* c = h->comm;
+  h->comm = nullptr;
+  if (c->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->comm);
+  if (c->stage) (void)hipFree(c->stage);
+  delete c;
+}
+
+extern "C" {
+
+int mt_comm_unique_id(void* id_out) {
+  MT_REQUIRE(nullptr, id_out != nullptr, "id_out is NULL");
+  Rccl* r = rccl();
+  if (!r) return fail(nullptr, MT_ERR_UNSUPPORTED, "RCCL is not available: " + g_rccl.error);
+  UniqueId id;
+  MT_NCCL(nullptr, r, r->GetUniqueId(&id));
+  std::memcpy(id_out, id.internal, MT_UNIQUE_ID_BYTES);
+  return MT_OK;
+}
+
+int mt_comm_init(mt_handle h, const void* unique_id, int rank, int world_size) {
+  MT_REQUIRE(nullptr, h != nullptr, "handle is NULL");
+  MT_REQUIRE(h, unique_id != nullptr, "unique_id is NULL");
+  MT_REQUIRE(h, world_size >= 1 && rank >= 0 && rank < world_size, "rank / world_size out of range");
+  if (h->comm) return fail(h, MT_ERR_STATE, "mt_comm_init: the handle already has a communicator");
+  Rccl* r = rccl();
+  if (!r) return fail(h, MT_ERR_UNSUPPORTED, "RCCL is not available: " + g_rccl.error);
+  MT_ON_DEVICE(h, h->cfg.device);
+  mt_comm* c = new (std::nothrow) mt_comm();
+  if (!c) return fail(h, MT_ERR_ALLOC, "out of host memory");
+  c->rank = rank;
+  c->world = world_size;
+  UniqueId id;
+  std::memcpy(id.internal, unique_id, MT_UNIQUE_ID_BYTES);
+  h->comm = c;  // from here on mt_comm_release cleans up
+#define MT_FAIL_INIT(stmt) \
+  do {                     \
+    int rc__ = (stmt);     \
+    if (rc__ != MT_OK) {   \
+      mt_comm_release(h);  \
+      return rc__;         \
+    }                      \
+  } while (0)
+  MT_FAIL_INIT([&]() -> int {
+    MT_NCCL(h, r, r->CommInitRank(&c->comm, world_size, id, rank));
+    // shard sizes of all ranks: one tiny all-gather through the staging buffer, once
+    int rc = MT_OK;
+    int64_t* d_counts = nullptr;
+    MT_HIP(h, hipMalloc(&d_counts, sizeof(int64_t) * (size_t)(world_size + 1)));
+    const int64_t mine = h->n;
+    hipError_t e = hipMemcpyAsync(d_counts + world_size, &mine, sizeof mine, hipMemcpyHostToDevice, h->stream);
+    int ne = kNcclSuccess;
+    if (e == hipSuccess) ne = r->AllGather(d_counts + world_size, d_counts, 1, kNcclInt64, c->comm, h->stream);
+    c->counts.assign((size_t)world_size, 0);
+    if (e == hipSuccess && ne == kNcclSuccess)
+      e = hipMemcpyAsync(c->counts.data(), d_counts, sizeof(int64_t) * (size_t)world_size, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess && ne == kNcclSuccess) e = hipStreamSynchronize(h->stream);
+    (void)hipFree(d_counts);
+    if (ne != kNcclSuccess) rc = fail(h, MT_ERR_HIP, std::string("ncclAllGather(counts): ") + r->GetErrorString(ne));
+    else if (e != hipSuccess) rc = fail(h, MT_ERR_HIP, std::string("mt_comm_init: ") + hipGetErrorString(e));
+    return rc;
+  }());
+#undef MT_FAIL_INIT
+  c->total = 0;
+  c->cmax = 0;
+  for (int64_t v : c->counts) {
+    c->total += v;
+    if (v > c->cmax) c->cmax = v;
+  }
+  c->equal = true;
+  for (int64_t v : c->counts) c->equal &= (v == c->cmax);
+  if (c->counts[(size_t)rank] != h->n) {
+    mt_comm_release(h);
+    return fail(h, MT_ERR_HIP, "mt_comm_init: the gathered shard sizes do not contain this rank's own");
+  }
+  if (!c->equal) {
+    if (hipMalloc(&c->stage, sizeof(float) * (size_t)(world_size + 1) * (size_t)c->cmax) != hipSuccess) {
+      (void)hipGetLastError();
+      mt_comm_release(h);
+      return fail(h, MT_ERR_ALLOC, "hipMalloc of the ragged-gather staging buffer failed");
+    }
+  }
+  return MT_OK;
+}
+
+int mt_comm_destroy(mt_handle h) {
+  MT_REQUIRE(nullptr, h != nullptr, "handle is NULL");
+  MT_ON_DEVICE(h, h->cfg.device);
+  MT_HIP(h, hipStreamSynchronize(h->stream));
+  mt_comm_release(h);
+  return MT_OK;
+}
+
+int mt_comm_total_envs(mt_handle h, int64_t* total) {
+  MT_REQUIRE(nullptr, h != nullptr, "handle is NULL");
+  MT_REQUIRE(h, total != nullptr, "total is NULL");
+  *total = h->comm ? h->comm->total : h->n;
+  return MT_OK;
+}
+
+int mt_gather_returns(mt_handle h, int field, int row, float* dst, int64_t dst_elems) {
+  MT_REQUIRE(nullptr, h != nullptr, "handle is NULL");
+  MT_REQUIRE(h, dst != nullptr, "dst is NULL");
+  const float* src = nullptr;
+  int rows = 1;
+  switch (field) {
+    case MT_F_TOTAL_REWARD: src = h->args.total_reward; break;
+    case MT_F_LAST_RETURN: src = h->args.last_return; break;
+    case MT_F_RETURN_RING:
+      src = h->args.ring;
+      rows = (int)h->args.ring_slots;
+      if (!src) return fail(h, MT_ERR_STATE, "MT_F_RETURN_RING: the handle was created with return_ring = 0");
+      break;
+    default: return fail(h, MT_ERR_INVALID_ARG, "mt_gather_returns: field must be TOTAL_REWARD, LAST_RETURN or RETURN_RING");
+  }
+  MT_REQUIRE(h, row >= 0 && row < rows, "row out of range");
+  src += (int64_t)row * h->ld;
+  MT_ON_DEVICE(h, h->cfg.device);
+  mt_comm* c = h->comm;
+  if (!c || c->world == 1) {
+    MT_REQUIRE(h, dst_elems == h->n, "dst_elems must be the total number of envs");
+    MT_HIP(h, hipMemcpyAsync(dst, src, sizeof(float) * (size_t)h->n, hipMemcpyDeviceToDevice, h->stream));
+    return MT_OK;
+  }
+  MT_REQUIRE(h, dst_elems == c->total, "dst_elems must be the total number of envs over all ranks");
+  Rccl* r = rccl();
+  if (!r) return fail(h, MT_ERR_UNSUPPORTED, "RCCL is not available: " + g_rccl.error);
+  if (c->equal) {  // straight from the arena row into the caller's buffer
+    MT_NCCL(h, r, r->AllGather(src, dst, (size_t)h->n, kNcclFloat32, c->comm, h->stream));
+    return MT_OK;
+  }
+  // ragged shards: pad to the largest shard, gather, then close the gaps
+  float* send = c->stage + (size_t)c->world * (size_t)c->cmax;
+  MT_HIP(h, hipMemsetAsync(send, 0, sizeof(float) * (size_t)c->cmax, h->stream));
+  MT_HIP(h, hipMemcpyAsync(send, src, sizeof(float) * (size_t)h->n, hipMemcpyDeviceToDevice, h->stream));
+  MT_NCCL(h, r, r->AllGather(send, c->stage, (size_t)c->cmax, kNcclFloat32, c->comm, h->stream));
+  int64_t off = 0;
+  for (int k = 0; k < c->world; ++k) {
+    MT_HIP(h, hipMemcpyAsync(dst + off, c->stage + (size_t)k * (size_t)c->cmax, sizeof(float) * (size_t)c->counts[(size_t)k],
+                             hipMemcpyDeviceToDevice, h->stream));
+    off += c->counts[(size_t)k];
+  }
+  return MT_OK;
+}
+
+}  // extern "C"

@@ -9,46 +9,21 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
 
+#include "engine_internal.h"
 #include "kernels.h"
 
 using namespace mt;
 
 namespace {
-
 thread_local std::string g_last_error;
-
 }  // namespace
 
-struct mt_engine {
-  mt_config cfg{};
-  int64_t n = 0, ld = 0;
-  int D = 0, K = 0;
-  hipStream_t own_stream = nullptr;
-  hipStream_t stream = nullptr;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  std::vector<hipEvent_t> lap_events;  // begin/end pairs recorded by mt_timer_lap_*; grown on demand
-  size_t laps_used = 0;                // events in use (2 per lap)
-  bool lap_open = false;
-  void* arena = nullptr;
-  size_t arena_bytes = 0;
-  void* staging = nullptr;
-  size_t staging_bytes = 0;
-  void* pinned = nullptr;  // page-locked host buffer of mt_step_host
-  size_t pinned_bytes = 0;
-  StepArgs args{};
-  bool is_reset = false;
-  int trig = 0;          // 0 recurrence, 1 polynomial sincos per sub-step, 2 hardware trig per sub-step
-  bool lds_table = false;
-  int static_kind = 0;   // 0 runtime table, 1 Ref4Table, 2 Dh7Table
-  std::string err;
-};
-
-namespace {
-
+namespace mt {
 int fail(mt_handle h, int code, const std::string& msg) {
   if (h)
     h->err = msg;
@@ -56,45 +31,9 @@ int fail(mt_handle h, int code, const std::string& msg) {
     g_last_error = msg;
   return code;
 }
+}  // namespace mt
 
-#define MT_HIP(h, call)                                                                        \
-  do {                                                                                         \
-    hipError_t e__ = (call);                                                                   \
-    if (e__ != hipSuccess)                                                                     \
-      return fail(h, MT_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e__));          \
-  } while (0)
-
-#define MT_REQUIRE(h, cond, msg) \
-  do {                           \
-    if (!(cond)) return fail(h, MT_ERR_INVALID_ARG, msg); \
-  } while (0)
-
-// Makes `device` current for the duration of a call and restores the caller's device afterwards, so that a handle
-// living on another GPU never changes what the calling thread (e.g. torch) considers current.
-class DeviceGuard {
- public:
-  explicit DeviceGuard(int device) {
-    if (hipGetDevice(&prev_) != hipSuccess) prev_ = -1;
-    err_ = (prev_ == device) ? hipSuccess : hipSetDevice(device);
-    changed_ = (err_ == hipSuccess && prev_ != device);
-  }
-  ~DeviceGuard() {
-    if (changed_ && prev_ >= 0) (void)hipSetDevice(prev_);
-  }
-  hipError_t error() const { return err_; }
-
- private:
-  int prev_ = -1;
-  hipError_t err_ = hipSuccess;
-  bool changed_ = false;
-};
-
-#define MT_ON_DEVICE(h, device)                                                                      \
-  DeviceGuard mt_guard__(device);                                                                    \
-  if (mt_guard__.error() != hipSuccess)                                                              \
-  return fail(h, MT_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(mt_guard__.error()))
-
-inline dim3 grid_for(int64_t n) { return dim3((unsigned)((n + kBlock - 1) / kBlock)); }
+namespace {
 
 DhConst make_dh(const float* table, int dof) {
   DhConst t{};
@@ -150,10 +89,10 @@ int match_static(const DhConst& t, int dof) {
 }
 
 template <class Tbl, bool LDS_OK>
-void launch_step_t(mt_handle h, bool sample) {
-  const dim3 g = grid_for(h->n), b(kBlock);
+void launch_step_t(mt_handle h, const StepArgs& args, bool sample) {
+  const dim3 g = grid_for(args.n), b(kBlock);
 #define MT_LAUNCH_STEP(SAMPLE_, TRIG_, LDS_) \
-  hipLaunchKernelGGL((step_kernel<Tbl, SAMPLE_, TRIG_, LDS_>), g, b, 0, h->stream, h->args)
+  hipLaunchKernelGGL((step_kernel<Tbl, SAMPLE_, TRIG_, LDS_>), g, b, 0, h->stream, args)
   if (LDS_OK && h->lds_table) {
     if constexpr (LDS_OK) {
       if (sample) MT_LAUNCH_STEP(true, 0, true); else MT_LAUNCH_STEP(false, 0, true);
@@ -172,23 +111,16 @@ void launch_step_t(mt_handle h, bool sample) {
 }
 
 template <int D>
-void launch_step_d(mt_handle h, bool sample) {
-  launch_step_t<RtTable<D>, true>(h, sample);
+void launch_step_d(mt_handle h, const StepArgs& args, bool sample) {
+  launch_step_t<RtTable<D>, true>(h, args, sample);
 }
 
-void launch_step(mt_handle h, bool sample) {
-  if (h->static_kind == 1) return launch_step_t<Ref4Table, false>(h, sample);
-  if (h->static_kind == 2) return launch_step_t<Dh7Table, false>(h, sample);
-  switch (h->D) {
-    case 2: return launch_step_d<2>(h, sample);
-    case 3: return launch_step_d<3>(h, sample);
-    case 4: return launch_step_d<4>(h, sample);
-    case 5: return launch_step_d<5>(h, sample);
-    case 6: return launch_step_d<6>(h, sample);
-    case 7: return launch_step_d<7>(h, sample);
-    case 8: return launch_step_d<8>(h, sample);
-    default: return;
-  }
+template <int D>
+void launch_trace_d(mt_handle h, const StepArgs& args, float* trace, bool sample) {
+  if (sample)
+    hipLaunchKernelGGL((trace_kernel<D, true>), grid_for(args.n), dim3(kBlock), 0, h->stream, args, trace);
+  else
+    hipLaunchKernelGGL((trace_kernel<D, false>), grid_for(args.n), dim3(kBlock), 0, h->stream, args, trace);
 }
 
 #define MT_DISPATCH_D(D_, FN, ...)   \
@@ -203,15 +135,48 @@ void launch_step(mt_handle h, bool sample) {
     default: break;                  \
   }
 
+// One env step of the envs `args` describes (the whole batch, or one env of it: args_for_env); `trace` is the
+// matching view of the sub-step trace buffer or NULL.
+void launch_step(mt_handle h, const StepArgs& args, float* trace, bool sample) {
+  if (trace) MT_DISPATCH_D(h->D, launch_trace_d, h, args, trace, sample);  // first: it needs the previous pose
+  if (h->static_kind == 1) return launch_step_t<Ref4Table, false>(h, args, sample);
+  if (h->static_kind == 2) return launch_step_t<Dh7Table, false>(h, args, sample);
+  MT_DISPATCH_D(h->D, launch_step_d, h, args, sample);
+}
+
+void launch_step(mt_handle h, bool sample) { launch_step(h, h->args, h->trace, sample); }
+
+// The view of ONE env of the batch: every row base moved `env` elements to the right, n = 1.  The wavefront ballot
+// of such a launch goes to a spare word; the real done_bits word is rebuilt afterwards (done_bits_word_kernel).
+StepArgs args_for_env(mt_handle h, int64_t env) {
+  StepArgs a = h->args;
+  a.actions += env;
+  a.goals += env;
+  a.points += env;
+  a.alive += env;
+  a.total_reward += env;
+  a.obs += env;
+  a.reward += env;
+  a.done += env;
+  a.done_bits = h->spare_bits;
+  a.ee += env;
+  a.episodes += env;
+  a.last_return += env;
+  if (a.ring) a.ring += env;
+  a.n = 1;
+  a.env_base += env;
+  return a;
+}
+
 template <int D>
-void launch_reset_d(mt_handle h, int mode) {  // 0 given points, 1 random, 2 random only-done
-  const dim3 g = grid_for(h->n), b(kBlock);
+void launch_reset_d(mt_handle h, const StepArgs& args, int mode) {  // 0 given points, 1 random, 2 random only-done
+  const dim3 g = grid_for(args.n), b(kBlock);
   if (mode == 0)
-    hipLaunchKernelGGL((reset_kernel<D, false, false>), g, b, 0, h->stream, h->args, h->cfg.radius);
+    hipLaunchKernelGGL((reset_kernel<D, false, false>), g, b, 0, h->stream, args, h->cfg.radius);
   else if (mode == 1)
-    hipLaunchKernelGGL((reset_kernel<D, true, false>), g, b, 0, h->stream, h->args, h->cfg.radius);
+    hipLaunchKernelGGL((reset_kernel<D, true, false>), g, b, 0, h->stream, args, h->cfg.radius);
   else
-    hipLaunchKernelGGL((reset_kernel<D, true, true>), g, b, 0, h->stream, h->args, h->cfg.radius);
+    hipLaunchKernelGGL((reset_kernel<D, true, true>), g, b, 0, h->stream, args, h->cfg.radius);
 }
 
 template <int D>
@@ -264,6 +229,14 @@ int field_info(mt_handle h, int field, FieldInfo* fi) {
     case MT_F_TOTAL_REWARD: *fi = {a.total_reward, 1, MT_F32, 4}; return MT_OK;
     case MT_F_EPISODES: *fi = {a.episodes, 1, MT_U32, 4}; return MT_OK;
     case MT_F_LAST_RETURN: *fi = {a.last_return, 1, MT_F32, 4}; return MT_OK;
+    case MT_F_RETURN_RING:
+      if (!a.ring) return fail(h, MT_ERR_STATE, "MT_F_RETURN_RING: the handle was created with return_ring = 0");
+      *fi = {a.ring, (int)a.ring_slots, MT_F32, 4};
+      return MT_OK;
+    case MT_F_TRACE:
+      if (!h->trace) return fail(h, MT_ERR_STATE, "MT_F_TRACE: the handle was created without MT_FLAG_TRACE");
+      *fi = {h->trace, 3 * h->cfg.substeps, MT_F32, 4};
+      return MT_OK;
     default: return fail(h, MT_ERR_INVALID_ARG, "unknown or non-resident field");
   }
 }
@@ -314,6 +287,8 @@ int mt_create(mt_handle* out, const mt_config* cfg) {
   MT_REQUIRE(nullptr, cfg->substeps >= 2, "substeps must be >= 2");
   MT_REQUIRE(nullptr, cfg->pickup_tol >= 0.f && cfg->radius > 0.f, "pickup_tol/radius out of range");
   MT_REQUIRE(nullptr, cfg->env_id_base >= 0, "env_id_base must be >= 0");
+  MT_REQUIRE(nullptr, cfg->return_ring >= 0 && cfg->return_ring <= MT_MAX_RETURN_RING, "return_ring must be in 0..64");
+  MT_REQUIRE(nullptr, cfg->reserved == 0, "mt_config.reserved must be 0");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
     (void)hipGetLastError();
@@ -371,7 +346,8 @@ int mt_create(mt_handle* out, const mt_config* cfg) {
   const size_t o_act = take(D * ld * 4), o_goal = take(D * ld * 4), o_pts = take(3 * K * ld * 4),
                o_obs = take(3 * K * ld * 4), o_alive = take(ld * 4), o_tot = take(ld * 4), o_rew = take(ld * 4),
                o_done = take(ld), o_bits = take(ld / 64 * 8), o_ee = take(3 * ld * 4), o_epi = take(ld * 4),
-               o_last = take(ld * 4);
+               o_last = take(ld * 4), o_ring = take((size_t)cfg->return_ring * ld * 4), o_misc = take(256),
+               o_trace = take((cfg->flags & MT_FLAG_TRACE) ? (size_t)cfg->substeps * 3 * ld * 4 : 0);
   h->arena_bytes = off;
   if (hipMalloc(&h->arena, h->arena_bytes) != hipSuccess) {
     (void)hipGetLastError();
@@ -392,6 +368,12 @@ int mt_create(mt_handle* out, const mt_config* cfg) {
   a.ee = (float*)(base + o_ee);
   a.episodes = (uint32_t*)(base + o_epi);
   a.last_return = (float*)(base + o_last);
+  a.ring = cfg->return_ring ? (float*)(base + o_ring) : nullptr;
+  a.ring_slots = (uint32_t)cfg->return_ring;
+  a.episode0 = 0;
+  a.bad_actions = (uint32_t*)(base + o_misc);                 // word 0 of the misc block
+  h->spare_bits = (unsigned long long*)(base + o_misc + 64);  // ballot sink of single-env launches
+  h->trace = (cfg->flags & MT_FLAG_TRACE) ? (float*)(base + o_trace) : nullptr;
   a.n = h->n;
   a.ld = h->ld;
   a.env_base = cfg->env_id_base;
@@ -411,6 +393,7 @@ int mt_destroy(mt_handle h) {
   if (!h) return MT_OK;
   DeviceGuard guard(h->cfg.device);
   (void)hipStreamSynchronize(h->stream);
+  mt_comm_release(h);
   if (h->staging) (void)hipFree(h->staging);
   if (h->pinned) (void)hipHostFree(h->pinned);
   if (h->arena) (void)hipFree(h->arena);
@@ -424,8 +407,17 @@ int mt_destroy(mt_handle h) {
 
 int mt_set_stream(mt_handle h, void* hip_stream) {
   MT_REQUIRE(nullptr, h != nullptr, "handle is NULL");
+  MT_ON_DEVICE(h, h->cfg.device);
+  MT_HIP(h, hipStreamSynchronize(h->stream));   // everything queued so far is finished before the ordering changes
+  h->stream = (hipStream_t)hip_stream;          // NULL is a stream too: the legacy default stream
+  return MT_OK;
+}
+
+int mt_use_own_stream(mt_handle h) {
+  MT_REQUIRE(nullptr, h != nullptr, "handle is NULL");
+  MT_ON_DEVICE(h, h->cfg.device);
   MT_HIP(h, hipStreamSynchronize(h->stream));
-  h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+  h->stream = h->own_stream;
   return MT_OK;
 }
 
@@ -461,7 +453,8 @@ int mt_reset(mt_handle h, const float* points, int layout, int is_device) {
     if (rc) return rc;
   }
   h->args.major = 0;  // caller-supplied targets start episode 0 of every env
-  MT_DISPATCH_D(h->D, launch_reset_d, h, 0);
+  h->args.episode0 = 0;
+  MT_DISPATCH_D(h->D, launch_reset_d, h, h->args, 0);
   int rc = check_launch(h, "reset_kernel");
   if (rc) return rc;
   if (!is_device) MT_HIP(h, hipStreamSynchronize(h->stream));  // the caller may free `points` on return
@@ -475,7 +468,8 @@ static int reset_random_impl(mt_handle h, uint64_t seed, uint32_t episode, int m
   h->args.seed_lo = (uint32_t)seed;
   h->args.seed_hi = (uint32_t)(seed >> 32);
   h->args.major = episode;
-  MT_DISPATCH_D(h->D, launch_reset_d, h, mode);
+  if (mode == 1) h->args.episode0 = episode;  // full reset: finished-episode counts restart from here
+  MT_DISPATCH_D(h->D, launch_reset_d, h, h->args, mode);
   int rc = check_launch(h, "reset_kernel");
   if (rc) return rc;
   h->is_reset = true;
@@ -613,6 +607,67 @@ int mt_step_random(mt_handle h, uint64_t seed, uint32_t step_idx) {
   return check_launch(h, "step_kernel");
 }
 
+// ---- one env of the batch (multienv.environment[i].step / .reset, manytor.py:82,118) ----------------------------
+static int rebuild_done_word(mt_handle h, int64_t env) {
+  hipLaunchKernelGGL(done_bits_word_kernel, dim3(1), dim3(64), 0, h->stream, h->args.done, h->n, env >> 6,
+                     h->args.done_bits);
+  return check_launch(h, "done_bits_word_kernel");
+}
+
+int mt_env_step(mt_handle h, int64_t env, const float* action, float* obs, int32_t* reward, uint8_t* done) {
+  MT_REQUIRE(nullptr, h != nullptr, "handle is NULL");
+  MT_REQUIRE(h, action && obs && reward && done, "NULL argument");
+  MT_REQUIRE(h, env >= 0 && env < h->n, "env index out of range");
+  if (!h->is_reset) return fail(h, MT_ERR_STATE, "mt_env_step before mt_reset / mt_reset_random");
+  MT_ON_DEVICE(h, h->cfg.device);
+  const StepArgs a = args_for_env(h, env);
+  const size_t pitch = (size_t)h->ld * 4;
+  // column `env` of the D action rows <- D host floats
+  MT_HIP(h, hipMemcpy2DAsync(a.actions, pitch, action, 4, 4, (size_t)h->D, hipMemcpyHostToDevice, h->stream));
+  launch_step(h, a, h->trace ? h->trace + env : nullptr, false);
+  int rc = check_launch(h, "step_kernel (one env)");
+  if (rc) return rc;
+  rc = rebuild_done_word(h, env);
+  if (rc) return rc;
+  MT_HIP(h, hipMemcpy2DAsync(obs, 4, a.obs, pitch, 4, (size_t)(3 * h->K), hipMemcpyDeviceToHost, h->stream));
+  MT_HIP(h, hipMemcpyAsync(reward, a.reward, 4, hipMemcpyDeviceToHost, h->stream));
+  MT_HIP(h, hipMemcpyAsync(done, a.done, 1, hipMemcpyDeviceToHost, h->stream));
+  MT_HIP(h, hipStreamSynchronize(h->stream));
+  return MT_OK;
+}
+
+int mt_env_reset(mt_handle h, int64_t env, const float* points, uint64_t seed, uint32_t episode) {
+  MT_REQUIRE(nullptr, h != nullptr, "handle is NULL");
+  MT_REQUIRE(h, env >= 0 && env < h->n, "env index out of range");
+  if (!h->is_reset) return fail(h, MT_ERR_STATE, "mt_env_reset before the first reset of the batch");
+  MT_ON_DEVICE(h, h->cfg.device);
+  StepArgs a = args_for_env(h, env);
+  if (points)  // (K, 3) host floats: flat index 3k + axis = row index
+    MT_HIP(h, hipMemcpy2DAsync(a.points, (size_t)h->ld * 4, points, 4, 4, (size_t)(3 * h->K), hipMemcpyHostToDevice,
+                               h->stream));
+  a.seed_lo = (uint32_t)seed;
+  a.seed_hi = (uint32_t)(seed >> 32);
+  a.major = episode;
+  MT_DISPATCH_D(h->D, launch_reset_d, h, a, points ? 0 : 1);
+  int rc = check_launch(h, "reset_kernel (one env)");
+  if (rc) return rc;
+  rc = rebuild_done_word(h, env);
+  if (rc) return rc;
+  MT_HIP(h, hipStreamSynchronize(h->stream));  // the caller may free `points` on return
+  return MT_OK;
+}
+
+int mt_bad_action_count(mt_handle h, uint64_t* count) {
+  MT_REQUIRE(nullptr, h != nullptr, "handle is NULL");
+  MT_REQUIRE(h, count != nullptr, "count is NULL");
+  MT_ON_DEVICE(h, h->cfg.device);
+  uint32_t c = 0;
+  MT_HIP(h, hipMemcpyAsync(&c, h->args.bad_actions, 4, hipMemcpyDeviceToHost, h->stream));
+  MT_HIP(h, hipStreamSynchronize(h->stream));
+  *count = c;
+  return MT_OK;
+}
+
 int mt_rollout(mt_handle h, int n_steps, uint64_t seed, uint32_t step_idx0) {
   MT_REQUIRE(nullptr, h != nullptr, "handle is NULL");
   MT_REQUIRE(h, n_steps >= 0, "n_steps must be >= 0");
@@ -630,7 +685,7 @@ int mt_rollout_fused(mt_handle h, int n_steps, uint64_t seed, uint32_t step_idx0
   if (n_steps == 0) return MT_OK;
   // The fused kernel implements the default trigonometry only; the measured alternatives run the same thing as a
   // sequence of launches.
-  const bool fusable = h->trig == 0 && !h->lds_table;
+  const bool fusable = h->trig == 0 && !h->lds_table && !h->trace;
   if (!fusable) {
     for (int s = 0; s < n_steps; ++s) {
       int rc = mt_step_random(h, seed, step_idx0 + (uint32_t)s);
@@ -696,6 +751,8 @@ static int64_t env_major_bytes(mt_handle h, int field) {
     case MT_F_DONE_BITS: return (n + 63) / 64 * 8;
     case MT_F_EE: return n * 3 * 4;
     case MT_F_JOINTS: return n * h->D * 3 * 4;
+    case MT_F_RETURN_RING: return h->args.ring ? n * (int64_t)h->args.ring_slots * 4 : -1;
+    case MT_F_TRACE: return h->trace ? n * (int64_t)h->cfg.substeps * 3 * 4 : -1;
     default: return -1;
   }
 }
@@ -704,7 +761,7 @@ int mt_get(mt_handle h, int field, void* dst, int64_t dst_bytes, int is_device) 
   MT_REQUIRE(nullptr, h != nullptr, "handle is NULL");
   MT_REQUIRE(h, dst != nullptr, "dst is NULL");
   const int64_t need = env_major_bytes(h, field);
-  MT_REQUIRE(h, need > 0, "unknown field");
+  MT_REQUIRE(h, need > 0, "unknown field (or a field this handle was created without)");
   MT_REQUIRE(h, dst_bytes == need, "dst_bytes does not match the field's env-major size");
   MT_ON_DEVICE(h, h->cfg.device);
   const dim3 g = grid_for(h->n), b(kBlock);
@@ -723,6 +780,8 @@ int mt_get(mt_handle h, int field, void* dst, int64_t dst_bytes, int is_device) 
     case MT_F_POINTS: hipLaunchKernelGGL((soa_to_env_major<float>), g, b, 0, h->stream, a.points, h->ld, 3 * h->K, h->n, (float*)out); break;
     case MT_F_OBS: hipLaunchKernelGGL((soa_to_env_major<float>), g, b, 0, h->stream, a.obs, h->ld, 3 * h->K, h->n, (float*)out); break;
     case MT_F_EE: hipLaunchKernelGGL((soa_to_env_major<float>), g, b, 0, h->stream, a.ee, h->ld, 3, h->n, (float*)out); break;
+    case MT_F_RETURN_RING: hipLaunchKernelGGL((soa_to_env_major<float>), g, b, 0, h->stream, a.ring, h->ld, (int)a.ring_slots, h->n, (float*)out); break;
+    case MT_F_TRACE: hipLaunchKernelGGL((soa_to_env_major<float>), g, b, 0, h->stream, h->trace, h->ld, 3 * h->cfg.substeps, h->n, (float*)out); break;
     case MT_F_ALIVE: hipLaunchKernelGGL(alive_unpack, g, b, 0, h->stream, a.alive, h->K, h->n, (uint8_t*)out); break;
     case MT_F_JOINTS: MT_DISPATCH_D(h->D, launch_joints_d, h, (float*)out); break;
     case MT_F_REWARD: direct = true; direct_src = a.reward; break;
@@ -849,19 +908,49 @@ int mt_timer_laps_total(mt_handle h, float* total_ms, int* n_laps) {
 }
 
 // ---- stateless helpers ------------------------------------------------------------------------
+// They have no handle to keep buffers on, so the device scratch they need is cached per device and only ever
+// grows; one lock serialises them (they are small synchronous calls on the null stream).
+namespace {
+struct Scratch {
+  void* p = nullptr;
+  size_t bytes = 0;
+};
+std::mutex g_scratch_mu;
+Scratch g_scratch[64];
+
+int scratch_reserve(int device, size_t bytes, void** out) {  // g_scratch_mu held, `device` current
+  if (device < 0 || device >= 64) return fail(nullptr, MT_ERR_INVALID_ARG, "device ordinal out of range");
+  Scratch& sc = g_scratch[device];
+  if (sc.bytes < bytes) {
+    if (sc.p) (void)hipFree(sc.p);
+    sc.p = nullptr;
+    sc.bytes = 0;
+    const size_t want = align_up(bytes, (size_t)1 << 16);
+    if (hipMalloc(&sc.p, want) != hipSuccess) {
+      (void)hipGetLastError();
+      sc.p = nullptr;
+      return fail(nullptr, MT_ERR_ALLOC, "hipMalloc of the helper scratch failed");
+    }
+    sc.bytes = want;
+  }
+  *out = sc.p;
+  return MT_OK;
+}
+}  // namespace
+
 int mt_fk_batch(int device, const float* dh_table, int dof, int mode, const float* angles, int angles_in_radians,
                 int64_t n, float* out_mat16) {
   MT_REQUIRE(nullptr, dh_table && angles && out_mat16, "NULL argument");
   MT_REQUIRE(nullptr, dof >= 1 && dof <= MT_MAX_DOF && mode >= 0 && mode <= dof, "dof/mode out of range");
   MT_REQUIRE(nullptr, n >= 1, "n must be >= 1");
   MT_ON_DEVICE(nullptr, device);
-  float *d_in = nullptr, *d_out = nullptr;
-  MT_HIP(nullptr, hipMalloc(&d_in, (size_t)n * dof * 4));
-  if (hipMalloc(&d_out, (size_t)n * 64) != hipSuccess) {
-    (void)hipFree(d_in);
-    return fail(nullptr, MT_ERR_ALLOC, "hipMalloc failed");
-  }
-  int rc = MT_OK;
+  std::lock_guard<std::mutex> lock(g_scratch_mu);
+  const size_t in_b = align_up((size_t)n * dof * 4, 256);
+  void* base = nullptr;
+  int rc = scratch_reserve(device, in_b + (size_t)n * 64, &base);
+  if (rc) return rc;
+  float* d_in = (float*)base;
+  float* d_out = (float*)((char*)base + in_b);
   FkArgs a{d_in, d_out, n, dof, mode, angles_in_radians, make_dh(dh_table, dof)};
   hipError_t e = hipMemcpy(d_in, angles, (size_t)n * dof * 4, hipMemcpyHostToDevice);
   if (e == hipSuccess) {
@@ -870,8 +959,6 @@ int mt_fk_batch(int device, const float* dh_table, int dof, int mode, const floa
   }
   if (e == hipSuccess) e = hipMemcpy(out_mat16, d_out, (size_t)n * 64, hipMemcpyDeviceToHost);
   if (e != hipSuccess) rc = fail(nullptr, MT_ERR_HIP, std::string("mt_fk_batch: ") + hipGetErrorString(e));
-  (void)hipFree(d_in);
-  (void)hipFree(d_out);
   return rc;
 }
 
@@ -881,23 +968,21 @@ int mt_route_trace(int device, const float* dh_table, int dof, int substeps, con
   MT_REQUIRE(nullptr, dof >= 2 && dof <= MT_MAX_DOF && substeps >= 2, "dof/substeps out of range");
   MT_REQUIRE(nullptr, n >= 1 && n * substeps < ((int64_t)1 << 31), "n out of range");
   MT_ON_DEVICE(nullptr, device);
-  const size_t in_b = (size_t)n * dof * 4, out_b = (size_t)n * substeps * dof * 3 * 4;
-  char* d = nullptr;
-  if (hipMalloc(&d, 2 * in_b + out_b) != hipSuccess) {
-    (void)hipGetLastError();
-    return fail(nullptr, MT_ERR_ALLOC, "hipMalloc failed");
-  }
-  int rc = MT_OK;
+  const size_t in_b = align_up((size_t)n * dof * 4, 256), out_b = (size_t)n * substeps * dof * 3 * 4;
+  std::lock_guard<std::mutex> lock(g_scratch_mu);
+  void* base = nullptr;
+  int rc = scratch_reserve(device, 2 * in_b + out_b, &base);
+  if (rc) return rc;
+  char* d = (char*)base;
   TraceArgs a{(const float*)d, (const float*)(d + in_b), (float*)(d + 2 * in_b), n, dof, substeps, make_dh(dh_table, dof)};
-  hipError_t e = hipMemcpy(d, prev, in_b, hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMemcpy(d + in_b, action, in_b, hipMemcpyHostToDevice);
+  hipError_t e = hipMemcpy(d, prev, (size_t)n * dof * 4, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d + in_b, action, (size_t)n * dof * 4, hipMemcpyHostToDevice);
   if (e == hipSuccess) {
     hipLaunchKernelGGL(route_trace_kernel, grid_for(n * substeps), dim3(kBlock), 0, 0, a);
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipMemcpy(out, d + 2 * in_b, out_b, hipMemcpyDeviceToHost);
   if (e != hipSuccess) rc = fail(nullptr, MT_ERR_HIP, std::string("mt_route_trace: ") + hipGetErrorString(e));
-  (void)hipFree(d);
   return rc;
 }
 
@@ -905,10 +990,12 @@ int mt_r_theta_batch(int device, const float* v1, const float* v2, int64_t n, fl
   MT_REQUIRE(nullptr, v1 && v2 && out_r_theta, "NULL argument");
   MT_REQUIRE(nullptr, n >= 1, "n must be >= 1");
   MT_ON_DEVICE(nullptr, device);
-  float* d = nullptr;
-  MT_HIP(nullptr, hipMalloc(&d, (size_t)n * 8 * 4));
+  std::lock_guard<std::mutex> lock(g_scratch_mu);
+  void* base = nullptr;
+  int rc = scratch_reserve(device, (size_t)n * 8 * 4, &base);
+  if (rc) return rc;
+  float* d = (float*)base;
   float *d1 = d, *d2 = d + 3 * n, *dout = d + 6 * n;
-  int rc = MT_OK;
   hipError_t e = hipMemcpy(d1, v1, (size_t)n * 12, hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(d2, v2, (size_t)n * 12, hipMemcpyHostToDevice);
   if (e == hipSuccess) {
@@ -917,7 +1004,6 @@ int mt_r_theta_batch(int device, const float* v1, const float* v2, int64_t n, fl
   }
   if (e == hipSuccess) e = hipMemcpy(out_r_theta, dout, (size_t)n * 8, hipMemcpyDeviceToHost);
   if (e != hipSuccess) rc = fail(nullptr, MT_ERR_HIP, std::string("mt_r_theta_batch: ") + hipGetErrorString(e));
-  (void)hipFree(d);
   return rc;
 }
 

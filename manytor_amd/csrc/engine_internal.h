@@ -1,0 +1,87 @@
+// Host-side state of one handle and the error/device helpers shared by engine.hip and comm.hip.
+// Internal: nothing in here is part of the C ABI (include/manytor_hip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "step_args.h"
+
+struct mt_comm;  // comm.hip: the RCCL communicator of a handle
+
+struct mt_engine {
+  mt_config cfg{};
+  int64_t n = 0, ld = 0;
+  int D = 0, K = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  std::vector<hipEvent_t> lap_events;  // begin/end pairs recorded by mt_timer_lap_*; grown on demand
+  size_t laps_used = 0;                // events in use (2 per lap)
+  bool lap_open = false;
+  void* arena = nullptr;
+  size_t arena_bytes = 0;
+  void* staging = nullptr;
+  size_t staging_bytes = 0;
+  void* pinned = nullptr;  // page-locked host buffer of mt_step_host
+  size_t pinned_bytes = 0;
+  mt::StepArgs args{};
+  float* trace = nullptr;  // [3S][ld] end-effector position per sub-step (MT_FLAG_TRACE), else NULL
+  unsigned long long* spare_bits = nullptr;  // where a single-env launch parks its wavefront ballot
+  bool is_reset = false;
+  int trig = 0;          // 0 recurrence, 1 polynomial sincos per sub-step, 2 hardware trig per sub-step
+  bool lds_table = false;
+  int static_kind = 0;   // 0 runtime table, 1 Ref4Table, 2 Dh7Table
+  mt_comm* comm = nullptr;
+  std::string err;
+};
+
+namespace mt {
+
+// Records `msg` where mt_last_error will find it (on the handle, or per thread when there is none).
+int fail(mt_handle h, int code, const std::string& msg);
+
+// Makes `device` current for the duration of a call and restores the caller's device afterwards, so that a handle
+// living on another GPU never changes what the calling thread (e.g. torch) considers current.
+class DeviceGuard {
+ public:
+  explicit DeviceGuard(int device) {
+    if (hipGetDevice(&prev_) != hipSuccess) prev_ = -1;
+    err_ = (prev_ == device) ? hipSuccess : hipSetDevice(device);
+    changed_ = (err_ == hipSuccess && prev_ != device);
+  }
+  ~DeviceGuard() {
+    if (changed_ && prev_ >= 0) (void)hipSetDevice(prev_);
+  }
+  hipError_t error() const { return err_; }
+
+ private:
+  int prev_ = -1;
+  hipError_t err_ = hipSuccess;
+  bool changed_ = false;
+};
+
+inline dim3 grid_for(int64_t n) { return dim3((unsigned)((n + kBlock - 1) / kBlock)); }
+
+}  // namespace mt
+
+#define MT_HIP(h, call)                                                                            \
+  do {                                                                                             \
+    hipError_t e__ = (call);                                                                       \
+    if (e__ != hipSuccess)                                                                         \
+      return mt::fail(h, MT_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e__));          \
+  } while (0)
+
+#define MT_REQUIRE(h, cond, msg)                              \
+  do {                                                        \
+    if (!(cond)) return mt::fail(h, MT_ERR_INVALID_ARG, msg); \
+  } while (0)
+
+#define MT_ON_DEVICE(h, device)                                                                          \
+  mt::DeviceGuard mt_guard__(device);                                                                    \
+  if (mt_guard__.error() != hipSuccess)                                                                  \
+  return mt::fail(h, MT_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(mt_guard__.error()))
+
+// comm.hip
+void mt_comm_release(mt_handle h);

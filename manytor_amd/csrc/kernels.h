@@ -16,13 +16,11 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include "../../include/manytor_hip.h"
 #include "mt_math.h"
 #include "philox.h"
+#include "step_args.h"
 
 namespace mt {
-
-constexpr int kBlock = 256;  // 4 wavefronts
 
 // Write-only outputs of a step (observations, reward, done, end effector) are never re-read by the next
 // step.  MT_NT_STORES marks them non-temporal so they do not displace the re-read state (goals, targets,
@@ -50,38 +48,6 @@ __device__ __forceinline__ void str_stream(T* row, uint32_t boff, T v) {
   *p = v;
 #endif
 }
-
-// Per-joint DH constants, uniform over the launch.  Passed by value in the
-// kernel arguments, so they live in SGPRs (s_load from the kernarg segment);
-// the MT_FLAG_DH_IN_LDS variant copies them to LDS first.
-struct DhConst {
-  float a[MT_MAX_DOF];
-  float d[MT_MAX_DOF];
-  float sa[MT_MAX_DOF];       // sin(alpha)
-  float ca[MT_MAX_DOF];       // cos(alpha)
-  float off_deg[MT_MAX_DOF];  // theta offset, degrees
-};
-
-struct StepArgs {
-  float* actions;                 // [D][ld]
-  float* goals;                   // [D][ld]
-  float* points;                  // [3K][ld]
-  uint32_t* alive;                // [ld] bit p = target p alive
-  float* total_reward;            // [ld]
-  float* obs;                     // [3K][ld]
-  int32_t* reward;                // [ld]
-  uint8_t* done;                  // [ld]
-  unsigned long long* done_bits;  // [ld/64]
-  float* ee;                      // [3][ld]
-  uint32_t* episodes;             // [ld] episode index of each env (keys its target draws)
-  float* last_return;             // [ld] return of the episode that ended at the last (auto-)reset
-  int64_t n, ld, env_base;
-  int32_t K, S;
-  float tol, inv_sm1;
-  uint32_t flags;
-  uint32_t seed_lo, seed_hi, major;  // RNG key + step / episode index
-  DhConst dh;
-};
 
 // ---------------------------------------------------------------------------
 // DH table views.  The chain code below is written once against this
@@ -365,6 +331,18 @@ __device__ __forceinline__ float route_kinematics(const Tbl& t, int S, float inv
   return zmin;
 }
 
+// An env finished its episode `episode` with return `ret` and is being re-armed: keep the return in the ring
+// (slot = number of episodes it finished before, modulo the ring size) and in the one-slot last_return row.
+__device__ __forceinline__ void record_finished(const StepArgs& a, uint32_t i, uint32_t episode, float ret) {
+  str(a.last_return, i * 4u, ret);
+  if (a.ring_slots) str(a.ring + (int64_t)((episode - a.episode0) % a.ring_slots) * a.ld, i * 4u, ret);
+}
+
+// Staged actions come from outside (a policy, a host array): anything that is not a finite angle of at most
+// 2^15 degrees in magnitude -- NaN, +-inf, garbage -- would poison `goals` for good.  Tested on the bit pattern,
+// so the check survives -ffinite-math-only.
+__device__ __forceinline__ bool unusable_angle(float v) { return (__float_as_uint(v) & 0x7FFFFFFFu) > 0x47000000u; }
+
 template <class Tbl, bool SAMPLE, int TRIG, bool LDS>
 __global__ __launch_bounds__(kBlock) void step_kernel(const StepArgs a) {
   constexpr int D = Tbl::D;
@@ -392,8 +370,17 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const StepArgs a) {
     // not stored separately: the action taken becomes `goals` below (manytor.py:184), 4D bytes of traffic saved
     draw_action<D>(((uint64_t)a.seed_hi << 32) | a.seed_lo, (uint64_t)(a.env_base + i), a.major, act);
   } else {
+    bool bad = false;
 #pragma unroll
-    for (int j = 0; j < D; ++j) act[j] = ldr(a.actions + j * ld, i * 4u);
+    for (int j = 0; j < D; ++j) {
+      act[j] = ldr(a.actions + j * ld, i * 4u);
+      bad |= unusable_angle(act[j]);
+    }
+    if (bad) {  // the env holds its pose this step; the call is counted (mt_bad_action_count)
+#pragma unroll
+      for (int j = 0; j < D; ++j) act[j] = g[j];
+      atomicAdd(a.bad_actions, 1u);
+    }
   }
 
   float el[3], e[3];
@@ -429,6 +416,58 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const StepArgs a) {
   str_stream(a.done, i, (uint8_t)(done ? 1 : 0));
   const unsigned long long bits = __ballot(done);
   if ((threadIdx.x & 63) == 0) a.done_bits[i >> 6] = bits;
+}
+
+// Sub-step trajectory of the whole batch (manytor.py:190 appends joints_coordinates[3] of every
+// sub-step to `trajectory`): the end effector at each of the S poses of the route goals -> action, as SoA rows
+// [3S][ld] (row 3k + axis).  Launched BEFORE the step kernel of the same call (it needs the previous pose) with the
+// same action source, only on handles created with MT_FLAG_TRACE: the timed step kernel is untouched.  Every pose gets
+// the full polynomial sincos, like route_trace_kernel.
+template <int D, bool SAMPLE>
+__global__ __launch_bounds__(kBlock) void trace_kernel(const StepArgs a, float* trace) {
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= a.n) return;
+  const int64_t ld = a.ld;
+  const RtTable<D> t{a.dh};
+  float g[D], act[D], st[D];
+#pragma unroll
+  for (int j = 0; j < D; ++j) g[j] = ldr(a.goals + j * ld, i * 4u);
+  if (SAMPLE) {
+    draw_action<D>(((uint64_t)a.seed_hi << 32) | a.seed_lo, (uint64_t)(a.env_base + i), a.major, act);
+  } else {
+    bool bad = false;
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      act[j] = ldr(a.actions + j * ld, i * 4u);
+      bad |= unusable_angle(act[j]);
+    }
+    if (bad) {
+#pragma unroll
+      for (int j = 0; j < D; ++j) act[j] = g[j];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < D; ++j) st[j] = (act[j] - g[j]) * a.inv_sm1;
+  for (int k = 0; k < a.S; ++k) {
+    float s[D], c[D], p[D][3];
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      const float pose = (k == a.S - 1) ? act[j] : __builtin_fmaf((float)k, st[j], g[j]);  // np.linspace, manytor.py:182
+      sincos_deg(pose + t.off(j), s[j], c[j]);
+    }
+    chain_all<RtTable<D>>(s, c, t, p);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) str_stream(trace + (int64_t)(3 * k + q) * ld, i * 4u, p[D - 1][q]);
+  }
+}
+
+// done_bits word `word` rebuilt from the done bytes: single-env launches (mt_env_step / mt_env_reset) cannot produce
+// the 64-env ballot themselves.  One wavefront.
+__global__ __launch_bounds__(64) void done_bits_word_kernel(const uint8_t* done, int64_t n, int64_t word,
+                                                            unsigned long long* done_bits) {
+  const int64_t i = word * 64 + threadIdx.x;
+  const unsigned long long bits = __ballot(i < n && done[i] != 0);
+  if (threadIdx.x == 0) done_bits[word] = bits;
 }
 
 // One rejection-sampling candidate of manytor.py:229-239 from one Philox block.
@@ -488,7 +527,10 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(const StepArgs a, float r
   const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= a.n) return;
   const int64_t ld = a.ld;
-  const bool go = ONLY_DONE ? (a.done[i] != 0) : true;
+  // done byte: 1 = finished, waiting for this call; 2 = finished and already re-armed inside mt_rollout_fused
+  const uint8_t dn = ONLY_DONE ? a.done[i] : (uint8_t)1;
+  const bool go = dn == 1;
+  if (ONLY_DONE && dn == 2) a.done[i] = 0;
   if (go) {
     float s[D], c[D], p[D][3];
 #pragma unroll
@@ -499,7 +541,10 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(const StepArgs a, float r
     chain_all<RtTable<D>>(s, c, RtTable<D>{a.dh}, p);  // joints_coordinates at the zero pose, manytor.py:224-225
 #pragma unroll
     for (int q = 0; q < 3; ++q) (a.ee + q * ld)[i] = p[D - 1][q];
-    a.last_return[i] = a.total_reward[i];
+    if (ONLY_DONE)
+      record_finished(a, i, a.episodes[i], a.total_reward[i]);
+    else
+      a.last_return[i] = a.total_reward[i];
     a.total_reward[i] = 0.f;
     a.reward[i] = 0;
     a.done[i] = 0;
@@ -558,7 +603,6 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(const StepArgs a, const
   uint32_t am = ldr(a.alive, i * 4u);
   float total = ldr(a.total_reward, i * 4u);
   uint32_t episode = r.auto_reset ? ldr(a.episodes, i * 4u) : 0u;
-  float last_ret = 0.f;
   bool ended = false, dirty = false;
   for (int k = 0; k < 3 * a.K; ++k) col[k * kBlock] = ldr(a.points + (int64_t)k * ld, i * 4u);
   const uint32_t all_alive = (a.K >= 32) ? 0xFFFFFFFFu : ((1u << a.K) - 1u);
@@ -599,12 +643,13 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(const StepArgs a, const
 #pragma unroll
     for (int q = 0; q < 3; ++q) str_stream(a.ee + q * ld, i * 4u, e[q]);
     str_stream(a.reward, i * 4u, rew);
-    str_stream(a.done, i, (uint8_t)(done ? 1 : 0));
+    // 2 = "finished in this step and already re-armed below": mt_reset_done must not re-arm it a second time
+    str_stream(a.done, i, (uint8_t)(done ? (r.auto_reset ? 2 : 1) : 0));
     const unsigned long long bits = __ballot(done);
     if ((threadIdx.x & 63) == 0) a.done_bits[i >> 6] = bits;
 
     if (done && r.auto_reset) {  // re-arm: what reset_kernel<.., RANDOM, ONLY_DONE> does in a separate launch
-      last_ret = total;
+      record_finished(a, i, episode, total);
       ended = true;
       total = 0.f;
       am = all_alive;
@@ -625,10 +670,7 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(const StepArgs a, const
   for (int j = 0; j < D; ++j) str(a.goals + j * ld, i * 4u, g[j]);
   str(a.alive, i * 4u, am);
   str(a.total_reward, i * 4u, total);
-  if (ended) {
-    str(a.episodes, i * 4u, episode);
-    str(a.last_return, i * 4u, last_ret);
-  }
+  if (ended) str(a.episodes, i * 4u, episode);
   if (dirty)
     for (int k = 0; k < 3 * a.K; ++k) str(a.points + (int64_t)k * ld, i * 4u, col[k * kBlock]);
 }

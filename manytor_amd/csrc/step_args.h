@@ -1,0 +1,47 @@
+// Argument blocks of the step kernels: plain structs shared by the kernels (kernels.h) and the host side
+// (engine_internal.h).  No device code in here.
+#pragma once
+#include <stdint.h>
+
+#include "../../include/manytor_hip.h"
+
+namespace mt {
+
+constexpr int kBlock = 256;  // 4 wavefronts
+
+// Per-joint DH constants, uniform over the launch.  Passed by value in the
+// kernel arguments, so they live in SGPRs (s_load from the kernarg segment);
+// the MT_FLAG_DH_IN_LDS variant copies them to LDS first.
+struct DhConst {
+  float a[MT_MAX_DOF];
+  float d[MT_MAX_DOF];
+  float sa[MT_MAX_DOF];       // sin(alpha)
+  float ca[MT_MAX_DOF];       // cos(alpha)
+  float off_deg[MT_MAX_DOF];  // theta offset, degrees
+};
+
+struct StepArgs {
+  float* actions;                 // [D][ld]
+  float* goals;                   // [D][ld]
+  float* points;                  // [3K][ld]
+  uint32_t* alive;                // [ld] bit p = target p alive
+  float* total_reward;            // [ld]
+  float* obs;                     // [3K][ld]
+  int32_t* reward;                // [ld]
+  uint8_t* done;                  // [ld]
+  unsigned long long* done_bits;  // [ld/64]
+  float* ee;                      // [3][ld]
+  uint32_t* episodes;             // [ld] episode index of each env (keys its target draws)
+  float* last_return;             // [ld] return of the episode that ended at the last (auto-)reset
+  float* ring;                    // [ring_slots][ld] returns of the episodes an env finished, slot = finished count % ring_slots
+  uint32_t* bad_actions;          // [1] number of (env, step) pairs whose staged action was not a usable angle
+  uint32_t ring_slots, episode0;  // episode0 = episode index every env got at the last full reset
+  int64_t n, ld, env_base;
+  int32_t K, S;
+  float tol, inv_sm1;
+  uint32_t flags;
+  uint32_t seed_lo, seed_hi, major;  // RNG key + step / episode index
+  DhConst dh;
+};
+
+}  // namespace mt

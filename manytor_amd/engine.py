@@ -63,7 +63,7 @@ class StepEngine:
 
     def __init__(self, n_envs, obj_number=10, dh_table=REF_DH_TABLE, substeps=25, pickup_tol=8.0, radius=51.3,
                  device=0, env_id_base=0, terminate_on_ground=False, hw_trig=False, dh_in_lds=False,
-                 direct_trig=False, specialize=True, ablate=0):
+                 direct_trig=False, specialize=True, ablate=0, return_ring=4, trace=False):
         self._lib = L.load()
         table = np.asarray(dh_table, dtype=np.float64)
         if table.ndim != 2 or table.shape[1] != 4:
@@ -85,10 +85,15 @@ class StepEngine:
         cfg.substeps = self.substeps
         cfg.flags = ((L.FLAG_TERMINATE_ON_GROUND if terminate_on_ground else 0) | (L.FLAG_HW_TRIG if hw_trig else 0)
                      | (L.FLAG_DH_IN_LDS if dh_in_lds else 0) | (L.FLAG_DIRECT_TRIG if direct_trig else 0)
-                     | (0 if specialize else L.FLAG_NO_SPECIALIZE)
+                     | (0 if specialize else L.FLAG_NO_SPECIALIZE) | (L.FLAG_TRACE if trace else 0)
                      | (L.FLAG_ABLATE_LOOP if ablate in (1, 2) else 0) | (L.FLAG_ABLATE_OBS if ablate in (2, 3) else 0))
         cfg.pickup_tol = float(pickup_tol)
         cfg.radius = float(radius)
+        cfg.return_ring = int(return_ring)
+        cfg.reserved = 0
+        self.return_ring_slots = int(return_ring)
+        self.has_trace = bool(trace)
+        self.episode0 = 0         # episode index every env got at the last full reset
         if self.dof > L.MT_MAX_DOF:
             raise ValueError(f"dof must be <= {L.MT_MAX_DOF}")
         flat = table.astype(np.float32).ravel()
@@ -123,12 +128,18 @@ class StepEngine:
 
     # ---- stream / sync / timing ---------------------------------------------------------------
     def set_stream(self, hip_stream):
-        """Run on a caller-owned hipStream_t (int / pointer); None restores the engine's own stream."""
-        self._call(self._lib.mt_set_stream, C.c_void_p(int(hip_stream)) if hip_stream else None)
+        """Run on a caller-owned hipStream_t (int / pointer).  0 is the legacy default stream (torch's default
+        stream); None goes back to the engine's own private stream, which is ordered against nothing else."""
+        if hip_stream is None:
+            self._call(self._lib.mt_use_own_stream)
+        else:
+            self._call(self._lib.mt_set_stream, C.c_void_p(int(hip_stream)))
 
     def use_torch_stream(self):
+        """Launch on torch's current stream of this device: torch ops on that stream (device_tensor views, RCCL
+        collectives) and engine launches then execute in program order, no manual sync needed."""
         import torch
-        self.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+        self.set_stream(int(torch.cuda.current_stream(self.device).cuda_stream))
 
     def sync(self):
         self._call(self._lib.mt_sync)
@@ -177,10 +188,22 @@ class StepEngine:
         else:
             p = np.ascontiguousarray(np.asarray(points, dtype=np.float32).reshape(n, k, 3))
             self._call(self._lib.mt_reset, p.ctypes.data_as(C.c_void_p), L.ENV_MAJOR, 0)
+        self.episode0 = 0
         self.version += 1
 
     def reset_random(self, seed=0x5EED, episode=0):
         self._call(self._lib.mt_reset_random, C.c_uint64(seed), C.c_uint32(episode))
+        self.episode0 = int(episode)
+        self.version += 1
+
+    def env_reset(self, env, points=None, seed=0x5EED, episode=0):
+        """``multienv.environment[env].reset()`` (manytor.py:82 + :219-253): reset ONE env; `points` (K, 3) or None
+        to draw them on the device."""
+        p = None
+        if points is not None:
+            p = np.ascontiguousarray(np.asarray(points, dtype=np.float32).reshape(self.obj_number, 3))
+        self._call(self._lib.mt_env_reset, C.c_int64(int(env)), p.ctypes.data_as(C.c_void_p) if p is not None else None,
+                   C.c_uint64(seed), C.c_uint32(episode))
         self.version += 1
 
     def reset_done(self, seed=0x5EED):
@@ -250,6 +273,23 @@ class StepEngine:
         self.version += 1
         return obs, rew, done.astype(bool)
 
+    def env_step(self, env, action):
+        """``multienv.environment[env].step(action)`` (manytor.py:82,118): step ONE env of the batch, the others are
+        untouched -> (obs2 (3K,) f32, reward int, done bool)."""
+        a = np.ascontiguousarray(np.asarray(action, dtype=np.float32).reshape(self.dof))
+        obs = np.empty(3 * self.obj_number, dtype=np.float32)
+        rew, done = C.c_int32(0), C.c_uint8(0)
+        self._call(self._lib.mt_env_step, C.c_int64(int(env)), a.ctypes.data_as(C.c_void_p), obs.ctypes.data_as(C.c_void_p),
+                   C.byref(rew), C.byref(done))
+        self.version += 1
+        return obs, int(rew.value), bool(done.value)
+
+    def bad_action_count(self) -> int:
+        """How many (env, step) pairs so far were handed a non-finite / absurd action and held their pose instead."""
+        c = C.c_uint64(0)
+        self._call(self._lib.mt_bad_action_count, C.byref(c))
+        return int(c.value)
+
     def step_random(self, seed=0x5EED, step_idx=0):
         self._call(self._lib.mt_step_random, C.c_uint64(seed), C.c_uint32(step_idx))
         self.version += 1
@@ -283,6 +323,7 @@ class StepEngine:
             L.F_DONE: ((n,), np.uint8), L.F_DONE_BITS: (((n + 63) // 64,), np.uint64), L.F_EE: ((n, 3), np.float32),
             L.F_TOTAL_REWARD: ((n,), np.float32), L.F_JOINTS: ((n, d, 3), np.float32),
             L.F_EPISODES: ((n,), np.uint32), L.F_LAST_RETURN: ((n,), np.float32),
+            L.F_RETURN_RING: ((n, self.return_ring_slots), np.float32), L.F_TRACE: ((n, self.substeps, 3), np.float32),
         }[field]
 
     def get(self, field) -> np.ndarray:
@@ -363,6 +404,56 @@ class StepEngine:
 
     def actions(self):
         return self.get(L.F_ACTIONS)
+
+    def return_ring(self):
+        """(N, R): slot c % R holds the return of the c-th episode the env finished since the last full reset."""
+        return self.get(L.F_RETURN_RING)
+
+    def finished(self):
+        """(N,) number of episodes each env has finished (re-armed by reset_done / auto_reset) since the last full reset."""
+        return (self.episodes() - np.uint32(self.episode0)).astype(np.int64)
+
+    def trace(self):
+        """(N, S, 3): end effector at each sub-step pose of the last step (needs trace=True; manytor.py:190)."""
+        return self.get(L.F_TRACE)
+
+    # ---- multi-GPU: the return gather (SURVEY 8e) -------------------------------------------------
+    def comm_init(self, unique_id: bytes, rank: int, world_size: int):
+        """Join the RCCL communicator named by `unique_id` (128 bytes from comm_unique_id() on rank 0).  Collective."""
+        if len(unique_id) != L.MT_UNIQUE_ID_BYTES:
+            raise ValueError("unique_id must be 128 bytes")
+        buf = C.create_string_buffer(bytes(unique_id), L.MT_UNIQUE_ID_BYTES)
+        self._call(self._lib.mt_comm_init, C.cast(buf, C.c_void_p), int(rank), int(world_size))
+
+    def comm_destroy(self):
+        self._call(self._lib.mt_comm_destroy)
+
+    def total_envs(self) -> int:
+        t = C.c_int64(0)
+        self._call(self._lib.mt_comm_total_envs, C.byref(t))
+        return int(t.value)
+
+    def gather_returns(self, out=None, field=None, row=0):
+        """All-gather one return row of every rank into `out`: a float32 device tensor of total_envs() elements (made
+        if None), global env order.  RCCL straight from the arena on the engine's stream; a device copy on one GPU.
+        Asynchronous: the result is ordered on the engine's stream (sync() or use_torch_stream() before reading)."""
+        import torch
+        field = L.F_TOTAL_REWARD if field is None else field
+        n_total = self.total_envs()
+        if out is None:
+            out = torch.empty(n_total, dtype=torch.float32, device=f"cuda:{self.device}")
+        if out.dtype != torch.float32 or not out.is_cuda or not out.is_contiguous() or out.numel() != n_total:
+            raise ValueError(f"out must be a contiguous float32 device tensor of {n_total} elements")
+        self._call(self._lib.mt_gather_returns, int(field), int(row), C.c_void_p(out.data_ptr()), C.c_int64(n_total))
+        return out
+
+
+def comm_unique_id() -> bytes:
+    """128 bytes naming a new RCCL communicator (call on rank 0, ship to the other ranks, then comm_init everywhere)."""
+    lib = L.load()
+    buf = C.create_string_buffer(L.MT_UNIQUE_ID_BYTES)
+    L.check(lib.mt_comm_unique_id(C.cast(buf, C.c_void_p)))
+    return buf.raw
 
 
 # ---- stateless helpers = module functions of the reference (manytor.py:17-53) -------------------

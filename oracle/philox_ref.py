@@ -75,8 +75,10 @@ def sample_actions(seed, env_ids, step_idx, dof):
 
 
 def sample_targets(seed, env_ids, episode_idx, obj_number, radius):
-    """(N, K, 3) float32 targets by per-env rejection sampling."""
+    """(N, K, 3) float32 targets by per-env rejection sampling.  `episode_idx`: one index for all envs or one per env
+    (envs re-armed on the device run on their own episode counters)."""
     lo, hi = _ctr(env_ids, TAG_TARGET)
+    episode_idx = np.asarray(episode_idx, dtype=np.uint64) & MASK
     n = lo.shape[0]
     r = np.float32(radius)
     r2 = np.float32(2.0) * r
@@ -86,7 +88,7 @@ def sample_targets(seed, env_ids, episode_idx, obj_number, radius):
     draw = 0
     scale = np.float32(2.0 ** -24)
     while (cnt < obj_number).any():
-        w = philox4x32_10(lo, hi, np.uint64(episode_idx & 0xFFFFFFFF), np.uint64(draw), seed & 0xFFFFFFFF, seed >> 32)
+        w = philox4x32_10(lo, hi, episode_idx, np.uint64(draw), seed & 0xFFFFFFFF, seed >> 32)
         u = [(w[j] >> np.uint32(8)).astype(np.float32) * scale for j in range(3)]
         x = r2 * u[0] - r
         y = r2 * u[1] - r

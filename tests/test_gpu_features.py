@@ -1,0 +1,230 @@
+"""GPU tests of the boundary features around the step path: stream ordering with torch, unusable actions, single-env
+step / reset inside a batch (multienv.environment[i], manytor.py:82,118), the device-side sub-step trace (manytor.py:190)
+and the C-ABI return gather (RCCL with one rank; a device copy without a communicator)."""
+import numpy as np
+import pytest
+
+from parity_util import DIST_TOL, POS_TOL
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def m():
+    import manytor_amd
+    if manytor_amd.device_count() < 1:
+        pytest.fail("gpu tests need a visible MI355X and the in-tree libmanytor_hip.so")
+    return manytor_amd
+
+
+def test_one_hip_runtime_in_the_process(m):
+    """torch bundles its own libamdhip64; the package loads that copy first so that torch and the engine share
+    streams, events and allocations whatever the import order (manytor_amd/_lib.py)."""
+    import torch  # noqa: F401
+    with open("/proc/self/maps") as f:
+        libs = {line.split()[-1] for line in f if "libamdhip64" in line}
+    assert len(libs) == 1, libs
+
+
+def test_torch_reads_are_ordered_after_queued_engine_work(m):
+    """with use_torch_stream() the engine launches on torch's current stream -- also when that is
+    the default stream (handle 0) -- so a torch read of a zero-copy view sees everything queued before it."""
+    import torch
+    n, k = 1048576, 7
+    eng = m.StepEngine(n, k)
+    eng.use_torch_stream()
+    eng.reset_random(3, 0)
+    eng.rollout(200, 3, 0)                                   # ~8 ms of queued kernels, no sync
+    view = eng.device_tensor(m.lib.F_TOTAL_REWARD)
+    snap = view.clone()                                      # torch op on the same stream: must run after the rollout
+    eng.reset_random(3, 1)                                   # zeroes the returns; must run after the clone
+    got = snap.cpu().numpy()
+    ref = m.StepEngine(n, k)
+    ref.reset_random(3, 0)
+    ref.rollout(200, 3, 0)
+    np.testing.assert_array_equal(got, ref.total_reward())
+    assert np.abs(got).max() > 0
+    np.testing.assert_array_equal(eng.total_reward(), np.zeros(n, dtype=np.float32))
+    # and on a side stream
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        eng.use_torch_stream()
+        eng.rollout(100, 3, 0)
+        snap2 = eng.device_tensor(m.lib.F_TOTAL_REWARD).clone()
+    side.synchronize()
+    ref.reset_random(3, 1)
+    ref.rollout(100, 3, 0)
+    np.testing.assert_array_equal(snap2.cpu().numpy(), ref.total_reward())
+    eng.set_stream(None)                                     # back to the private stream
+    eng.rollout(3, 3, 100)
+    eng.sync()
+
+
+def test_unusable_actions_hold_the_pose_and_are_counted(m):
+    """A NaN / inf / absurd action (a diverging policy) must not poison `goals` for good."""
+    n, k = 512, 3
+    eng = m.StepEngine(n, k)
+    pts = np.random.RandomState(0).uniform(-30, 30, size=(n, k, 3)).astype(np.float32)
+    pts[..., 2] = np.abs(pts[..., 2])
+    eng.reset(pts)
+    first = np.random.RandomState(1).randint(-90, 90, size=(n, 4)).astype(np.float32)
+    eng.step(first)
+    assert eng.bad_action_count() == 0
+    ref = m.StepEngine(n, k)
+    ref.reset(pts)
+    ref.step(first)
+    act = np.random.RandomState(2).randint(-90, 90, size=(n, 4)).astype(np.float32)
+    bad = act.copy()
+    bad[3, 1] = np.nan
+    bad[77, 0] = np.inf
+    bad[200, 3] = -np.inf
+    bad[301, 2] = 1e30
+    hold = act.copy()
+    for i in (3, 77, 200, 301):
+        hold[i] = first[i]                                   # expected behaviour: the env keeps its pose
+    eng.step(bad)
+    ref.step(hold)
+    assert eng.bad_action_count() == 4
+    for f in ("F_GOALS", "F_OBS", "F_REWARD", "F_DONE", "F_ALIVE", "F_EE", "F_TOTAL_REWARD"):
+        np.testing.assert_array_equal(eng.get(getattr(m.lib, f)), ref.get(getattr(m.lib, f)), err_msg=f)
+    assert np.isfinite(eng.goals()).all() and np.isfinite(eng.obs()).all()
+    big_ok = act.copy()
+    big_ok[5] = [720.0, -1080.0, 32768.0, -32768.0]          # large but usable: whole turns, same pose as 0
+    eng.step(big_ok)
+    assert eng.bad_action_count() == 4
+
+
+def test_single_env_step_and_reset_inside_a_batch(m):
+    """multienv.environment[i].step(a) / .reset() in the reference touch only env i (manytor.py:82,118)."""
+    n, k = 300, 5
+    rng = np.random.RandomState(4)
+    pts = rng.uniform(-30, 30, size=(n, k, 3)).astype(np.float32)
+    pts[..., 2] = np.abs(pts[..., 2])
+    a, b = m.StepEngine(n, k, pickup_tol=25.0), m.StepEngine(n, k, pickup_tol=25.0)
+    a.reset(pts)
+    b.reset(pts)
+    fields = ("F_GOALS", "F_OBS", "F_REWARD", "F_DONE", "F_ALIVE", "F_EE", "F_TOTAL_REWARD", "F_POINTS", "F_DONE_BITS")
+    acts = rng.randint(-180, 180, size=(n, 4)).astype(np.float32)
+    a.step(acts)                                             # batch step
+    for i in range(n):                                       # the same, one env at a time
+        obs, rew, done = b.env_step(i, acts[i])
+        assert obs.shape == (3 * k,) and isinstance(rew, int) and isinstance(done, bool)
+    for f in fields:
+        np.testing.assert_array_equal(a.get(getattr(m.lib, f)), b.get(getattr(m.lib, f)), err_msg=f)
+    # stepping one env leaves the others alone
+    before = {f: b.get(getattr(m.lib, f)) for f in fields}
+    obs, rew, done = b.env_step(129, [10, 20, 30, 40])
+    after = {f: b.get(getattr(m.lib, f)) for f in fields}
+    others = np.arange(n) != 129
+    for f in fields[:-1]:
+        np.testing.assert_array_equal(after[f][others], before[f][others], err_msg=f)
+    np.testing.assert_array_equal(after["F_GOALS"][129], [10, 20, 30, 40])
+    np.testing.assert_array_equal(obs, after["F_OBS"][129])
+    bits = after["F_DONE_BITS"]
+    unpacked = ((bits[:, None] >> np.arange(64, dtype=np.uint64)) & np.uint64(1)).astype(bool).ravel()[:n]
+    np.testing.assert_array_equal(unpacked, after["F_DONE"].astype(bool))
+    # reset of one env: given targets, and device-drawn ones
+    from oracle import philox_ref as px
+    newp = rng.uniform(0, 20, size=(k, 3)).astype(np.float32)
+    b.env_reset(7, newp)
+    np.testing.assert_array_equal(b.points()[7], newp)
+    assert np.all(b.goals()[7] == 0) and b.total_reward()[7] == 0 and b.alives()[7].all()
+    b.env_reset(8, None, seed=99, episode=5)
+    np.testing.assert_array_equal(b.points()[8], px.sample_targets(99, np.array([8], dtype=np.uint64), 5, k, 51.3)[0])
+    keep = np.ones(n, dtype=bool)
+    keep[[7, 8]] = False
+    np.testing.assert_array_equal(b.points()[keep], after["F_POINTS"][keep])
+    np.testing.assert_array_equal(b.goals()[keep], after["F_GOALS"][keep])
+    with pytest.raises(ValueError):
+        b.env_step(n, [0, 0, 0, 0])
+
+
+def test_multienv_environment_items_have_the_reference_methods(m, golden):
+    """`multienv.environment[i]` is an Environment in the reference (manytor.py:82): step / reset / action /
+    action_sample / is_done / get_observations work per env."""
+    g = golden("f5_semantics_kat")
+    pts = g["all_picked__points_in"]
+    np.random.seed(0)
+    me = m.Multienv((2, 2), len(pts))
+    me.reset()
+    e2 = me.environment[2]
+    e2.points = pts
+    np.testing.assert_allclose(e2.points, pts, atol=1e-5)
+    assert e2.is_done() is False
+    obs2, reward, done = e2.step([30, 45, -60, 90])
+    assert (reward, done) == (int(g["all_picked__reward"][0]), bool(g["all_picked__done"][0]))
+    np.testing.assert_allclose(obs2[0::3], g["all_picked__obs2"][0][0::3], atol=DIST_TOL)
+    assert e2.total_reward == 1.0 and me.environment[1].total_reward == 0.0
+    assert np.all(me.environment[1].goals == 0)              # the neighbours did not move
+    a = e2.action_sample()
+    assert len(a) == 4 and all(-180 <= int(v) < 180 for v in a)
+    reward2, obs3 = e2.action([10, 10, 10, 10], None)
+    assert reward2 == 0 and e2.total_reward == 1.0           # action() does not accumulate (manytor.py:258 is in step)
+    e2.reset()
+    assert e2.total_reward == 0.0 and e2.alives.all() and np.all(e2.goals == 0)
+    assert e2.get_observations().shape == (3 * len(pts),)
+
+
+def test_device_trace_buffer_matches_reference_substeps(m, golden):
+    """MT_F_TRACE: the end effector at each of the 25 sub-step poses, for the whole batch, vs
+    fixture F3 (the rows the reference appends to `trajectory`, manytor.py:190)."""
+    g = golden("f3_substep_trace")
+    n = len(g["prev"])
+    eng = m.StepEngine(n, 1, trace=True)
+    eng.reset(np.full((n, 1, 3), 1000.0, dtype=np.float32))
+    eng.set(m.lib.F_GOALS, g["prev"].astype(np.float32))
+    eng.step(g["action"])
+    tr = eng.trace()
+    assert tr.shape == (n, 25, 3)
+    assert np.abs(tr - g["jc"][:, :, 3, :]).max() <= POS_TOL
+    assert np.abs(tr[:, -1] - eng.ee()).max() <= 2e-5
+    # the trace does not change the step's results
+    plain = m.StepEngine(n, 1)
+    plain.reset(np.full((n, 1, 3), 1000.0, dtype=np.float32))
+    plain.set(m.lib.F_GOALS, g["prev"].astype(np.float32))
+    plain.step(g["action"])
+    for f in ("F_GOALS", "F_OBS", "F_REWARD", "F_EE", "F_TOTAL_REWARD"):
+        np.testing.assert_array_equal(eng.get(getattr(m.lib, f)), plain.get(getattr(m.lib, f)), err_msg=f)
+    with pytest.raises(m.ManytorError):
+        plain.trace()
+    # random-action path and a fused request (falls back to per-step launches so that the trace stays complete)
+    big = m.StepEngine(5000, 3, trace=True)
+    big.reset_random(1, 0)
+    prev = big.goals()
+    big.rollout_fused(2, 1, 0)
+    last_prev = big.goals().copy()
+    big.step_random(1, 2)
+    tr = big.trace()
+    ref = m.route_trace(last_prev[:64], big.goals()[:64])[:, :, -1, :]
+    assert np.abs(tr[:64] - ref).max() <= 2e-5
+    assert prev.shape == last_prev.shape
+
+
+def test_gather_returns_without_and_with_a_one_rank_rccl_communicator(m):
+    """mt_gather_returns: device copy without a communicator; with mt_comm_init(world = 1 ... RCCL really loaded and
+    a communicator really built) the same values.  Multi-rank behaviour is covered by the gloo world-2 CPU test of
+    the host logic; an 8-GPU node is not available to this box."""
+    import torch
+    n = 70001
+    eng = m.StepEngine(n, 7, return_ring=2)
+    eng.reset_random(2, 0)
+    eng.rollout(5, 2, 0)
+    out = eng.gather_returns()
+    eng.sync()
+    ref = eng.total_reward()
+    np.testing.assert_array_equal(out.cpu().numpy(), ref)
+    assert eng.total_envs() == n
+    uid = m.comm_unique_id()
+    assert len(uid) == 128 and any(uid)
+    eng.comm_init(uid, 0, 1)
+    assert eng.total_envs() == n
+    out2 = torch.zeros(n, dtype=torch.float32, device="cuda")
+    eng.gather_returns(out2)
+    eng.gather_returns(out, field=m.lib.F_LAST_RETURN)
+    eng.sync()
+    np.testing.assert_array_equal(out2.cpu().numpy(), ref)
+    np.testing.assert_array_equal(out.cpu().numpy(), eng.last_return())
+    with pytest.raises(ValueError):
+        eng.gather_returns(torch.zeros(n - 1, dtype=torch.float32, device="cuda"))
+    eng.comm_destroy()
+    eng.close()

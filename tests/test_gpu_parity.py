@@ -13,11 +13,9 @@ Bit-exact: device RNG streams vs oracle/philox_ref.py, staged actions, goals, sh
 import numpy as np
 import pytest
 
-pytestmark = pytest.mark.gpu
+from parity_util import DIST_TOL, GUARD, POS_TOL, assert_obs_close
 
-POS_TOL = 1e-4
-DIST_TOL = 2e-4
-GUARD = 1e-3
+pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture(scope="module")
@@ -32,26 +30,6 @@ def m():
 def mo():
     from oracle import manytor_oracle
     return manytor_oracle
-
-
-def assert_obs_close(obs, ref_obs, elbow, points, alive):
-    """obs, ref_obs (N,3K); elbow (N,3), points (N,K,3) and alive (N,K) from the oracle (pre-pickup state)."""
-    n, k = alive.shape
-    o = obs.reshape(n, k, 3).astype(np.float64)
-    r = ref_obs.reshape(n, k, 3)
-    m_ = np.abs(elbow[:, None, :] - points)
-    rho_xy = np.hypot(m_[..., 0], m_[..., 1])
-    dist = r[..., 0]
-    with np.errstate(divide="ignore"):
-        tol_r = np.maximum(1e-3, 57.3 * 1e-4 / rho_xy)
-        tol_th = np.maximum(1e-3, 57.3 * 1e-4 / dist)
-    dead = ~alive
-    assert np.all(o[dead] == 0.0)
-    assert np.all(np.abs(o[..., 0] - r[..., 0])[alive] <= DIST_TOL), np.abs(o[..., 0] - r[..., 0])[alive].max()
-    err_r = np.abs(o[..., 1] - r[..., 1])
-    err_t = np.abs(o[..., 2] - r[..., 2])
-    assert np.all((err_r <= tol_r)[alive]), (err_r - tol_r)[alive].max()
-    assert np.all((err_t <= tol_th)[alive]), (err_t - tol_th)[alive].max()
 
 
 class Lockstep:
