@@ -9,7 +9,14 @@ One "step" = one Environment.step() (manytor.py:255-260: 25 interpolated sub-ste
 kinematics, ground flag, observation, pickup, reward, return) for EVERY env of the batch, with the
 random action drawn in the same launch (manytor.py:215-217).  Inputs are synthetic and already
 resident in HBM when the timed region starts.  Every `episode_len` steps the returns are gathered
-over the ranks (RCCL all-gather, the only collective) and all envs are reset (test_multi.py:32-34).
+over the ranks (mt_gather_returns: RCCL all-gather straight from the arena, the only collective) and
+all envs are reset (test_multi.py:32-34).
+
+Timing protocol (robust to short --steps): a time-based pre-warm brings the GPU to its steady clock,
+then W untimed warm-up steps, then the region of EXACTLY K steps -- bracketed by barrier +
+torch.cuda.synchronize() on both sides, max over ranks -- is run `repeats` times; `ms_per_step` /
+`value` come from the MEDIAN region (min / max beside it).  Kernel time is measured with HIP events on
+the engine's stream around the step launches of every region.
 
 Prints ONE JSON line on rank 0 (contract: see the task brief / DESIGN.md section "Measurement").
 """
@@ -17,6 +24,7 @@ from __future__ import annotations
 
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -28,6 +36,8 @@ sys.path.insert(0, ROOT)
 
 METRIC = "env-steps/sec (whole node), 1M parallel 4-DoF arms, random actions"
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+MIN_TIMED_S = 0.05           # the repeated timed regions together cover at least this much GPU work
+PREWARM_S = 0.3
 
 
 def algorithmic_bytes_per_env_step(dof, k):
@@ -36,34 +46,60 @@ def algorithmic_bytes_per_env_step(dof, k):
     return 12 * dof + 24 * k + 33
 
 
-def cpu_baseline(dof_table, k, budget_s=12.0, n=65536, threads=16):
+def actual_bytes_per_env_step(dof, k):
+    """What mt_step_random really moves: the action is drawn in-kernel, so the 4D-byte action read of the
+    SURVEY model does not happen (PMC traffic agrees: profiles/traffic.json)."""
+    return algorithmic_bytes_per_env_step(dof, k) - 4 * dof
+
+
+def usable_cores():
+    """Host cores this process may really use: the affinity mask, capped by the cgroup CPU quota (the GPU box gives a
+    one-GPU job a 16-core share of its 256 cores; oversubscribing a quota only adds throttling noise)."""
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    why = "sched_getaffinity"
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            q = max(1, int(math.ceil(int(quota) / int(period))))
+            if q < cores:
+                cores, why = q, "cgroup cpu.max quota"
+    except (OSError, ValueError):
+        pass
+    return cores, why
+
+
+def cpu_baseline(dof_table, k, budget_s=12.0, n=65536):
     """The CPU port of the step path (oracle/: parity-checked against the reference's fixtures), timed on this box's
-    host cores on a bounded sample of the same workload.  Headline figure: the C restatement with OpenMP on the
-    box's CPU share; beside it the vectorised-numpy and the scalar (reference-shaped) Python figures on one core.
-    Baseline, not the target."""
+    host cores on a bounded sample of the same workload.  Headline figure: the C restatement with OpenMP on every
+    core this process may use; beside it the vectorised-numpy and the scalar (reference-shaped) Python figures on one
+    core.  Baseline, not the target."""
     from oracle import c_oracle
     from oracle import manytor_oracle as mo
     from oracle import philox_ref as px
     table = np.asarray(dof_table)
     dof = table.shape[0]
-    threads = max(1, min(threads, os.cpu_count() or 1))
+    threads, why = usable_cores()
     # (a) C + OpenMP
     nc = 1 << 20
     idc = np.arange(nc, dtype=np.uint64)
     cora = c_oracle.COracle(nc, k, table=table, threads=threads)
-    cora.reset(px.sample_targets(0x5EED, idc, 0, k, 51.3).astype(np.float64))
+    rng = np.random.RandomState(0)
+    pts = rng.uniform(-30, 30, size=(nc, k, 3))
+    pts[..., 2] = np.abs(pts[..., 2])
+    cora.reset(pts)
     cacts = [px.sample_actions(0x5EED, idc, t, dof).astype(np.float64) for t in range(4)]
     cora.step(cacts[0])
     t0 = time.perf_counter()
     csteps = 0
-    while csteps < 1 or (time.perf_counter() - t0 < budget_s and csteps < 200):
+    while csteps < 1 or (time.perf_counter() - t0 < budget_s and csteps < 400):
         cora.step(cacts[csteps % 4])
         csteps += 1
     dt_c = time.perf_counter() - t0
     # (b) vectorised numpy, one core
     ids = np.arange(n, dtype=np.uint64)
     ora = mo.BatchOracle(n, k, table=table)
-    ora.reset(px.sample_targets(0x5EED, ids, 0, k, 51.3).astype(np.float64))
+    ora.reset(pts[:n])
     acts = [px.sample_actions(0x5EED, ids, t, dof).astype(np.float64) for t in range(16)]
     ora.step(acts[0])
     t0 = time.perf_counter()
@@ -74,8 +110,7 @@ def cpu_baseline(dof_table, k, budget_s=12.0, n=65536, threads=16):
     dt = time.perf_counter() - t0
     # (c) the reference's own shape of the computation: one env at a time, three FK chains per sub-step (manytor.py:188)
     envs = [mo.ScalarEnv(k, table=table) for _ in range(16)]
-    pts = px.sample_targets(0x5EED, ids[:16], 0, k, 51.3)
-    for e, p in zip(envs, pts):
+    for e, p in zip(envs, pts[:16]):
         e.reset(points=p)
     t1 = time.perf_counter()
     for t in range(12):
@@ -85,7 +120,8 @@ def cpu_baseline(dof_table, k, budget_s=12.0, n=65536, threads=16):
     return {
         "value": nc * csteps / dt_c, "unit": "env-steps/s", "cores": threads, "kind": "port",
         "sample": f"{nc} envs x {csteps} steps, C restatement of the reference with OpenMP (oracle/manytor_oracle.c), "
-                  f"{dt_c:.1f} s on {threads} of {os.cpu_count()} host cores",
+                  f"{dt_c:.1f} s on {threads} threads = every core this process may use ({why}; os.cpu_count() = "
+                  f"{os.cpu_count()})",
         "numpy_vectorised_value_1core": n * steps / dt,
         "numpy_vectorised_sample": f"{n} envs x {steps} steps, oracle BatchOracle fp64, {dt:.1f} s",
         "scalar_faithful_value_1core": 16 * 12 / dt_scalar,
@@ -111,7 +147,8 @@ def measured_copy_bandwidth(torch, nbytes=1 << 30, reps=20):
 
 
 def load_traffic(workload_key):
-    """HBM bytes per step launch from the committed PMC run (profiles/), or None."""
+    """HBM bytes per step launch from the committed PMC run (profiles/traffic.json), or None.  PMC counters need
+    their own rocprofv3 passes, so this figure cannot be taken inside a bench run; `traffic_source` says so."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         with open(path) as f:
@@ -120,21 +157,129 @@ def load_traffic(workload_key):
         return None
 
 
+class EpisodeLoop:
+    """The benchmark's control flow, the shape of test_multi.py:17-34: `episode_len` random-action steps, then gather
+    the returns of all ranks and reset every env.  `engine` needs rollout / rollout_fused / reset_random /
+    gather_returns / lap_begin / lap_end (manytor_amd.StepEngine; a stand-in in the CPU rehearsal test)."""
+
+    def __init__(self, engine, seed, episode_len, fused=False):
+        self.eng, self.seed, self.L, self.fused = engine, seed, int(episode_len), fused
+        self.step = 0
+        self.episode = 0
+        self.gathers = 0
+        self.gathered = None
+        self.eng.reset_random(seed, 0)
+
+    def run(self, count, time_kernels=False):
+        """`count` env steps.  Returns (step launches timed, gathers done) of this call."""
+        done = launches = gathers = 0
+        while done < count:
+            seg = min(count - done, self.L - self.step % self.L)
+            if time_kernels:
+                self.eng.lap_begin("step")      # HIP events on the engine's stream, no host synchronisation
+            if self.fused:
+                self.eng.rollout_fused(seg, self.seed, self.step)
+            else:
+                self.eng.rollout(seg, self.seed, self.step)
+            if time_kernels:
+                self.eng.lap_end("step")
+                launches += seg
+            self.step += seg
+            done += seg
+            if self.step % self.L == 0:
+                if time_kernels:
+                    self.eng.lap_begin("gather")
+                self.gathered = self.eng.gather_returns(self.gathered)     # RCCL all-gather (device copy at N = 1)
+                if time_kernels:
+                    self.eng.lap_end("gather")
+                gathers += 1
+                self.episode += 1
+                self.eng.reset_random(self.seed, self.episode)
+        self.gathers += gathers
+        return launches, gathers
+
+
+class TimedEngine:
+    """StepEngine plus two named HIP-event lap timers (step launches, gathers) for EpisodeLoop."""
+
+    def __init__(self, eng):
+        self.e = eng
+        self.ms = {"step": 0.0, "gather": 0.0}
+        self._open = None
+
+    def __getattr__(self, name):
+        return getattr(self.e, name)
+
+    def lap_begin(self, what):
+        self._open = what
+        self.e.lap_begin()
+
+    def lap_end(self, what):
+        self.e.lap_end()
+        # one synchronisation-free event pair per lap; totals are read per kind at region end (collect)
+        self._kinds.append(what)
+
+    _kinds = None
+
+    def start_region(self):
+        self._kinds = []
+
+    def collect(self):
+        """Per-kind device milliseconds of the laps since start_region (synchronises once)."""
+        ms = self.e.lap_times()
+        out = {"step": 0.0, "gather": 0.0}
+        for kind, v in zip(self._kinds, ms):
+            out[kind] += v
+        self._kinds = []
+        return out
+
+
+def time_step_launches(m, n, table, radius, k, dev, seed, fused_len=0, launches=600):
+    """us per step of a secondary configuration: pre-warmed, HIP events around `launches` step launches."""
+    e = m.StepEngine(n, k, dh_table=table, radius=radius, device=dev)
+    e.reset_random(seed, 0)
+    t0 = time.perf_counter()
+    s = 0
+    while time.perf_counter() - t0 < 0.15:
+        e.rollout(200, seed, s)
+        s += 200
+        e.sync()
+    e.timer_start()
+    if fused_len:
+        for r in range(max(1, launches // fused_len)):
+            e.rollout_fused(fused_len, seed, s + r * fused_len)
+        steps = max(1, launches // fused_len) * fused_len
+    else:
+        e.rollout(launches, seed, s)
+        steps = launches
+    us = e.timer_stop() * 1e3 / steps
+    e.close()
+    return us
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--envs-per-gpu", type=int, default=1048576)
+    ap.add_argument("--envs-per-gpu", type=int, default=1048576, help="weak scaling (default): arms owned by every GPU")
+    ap.add_argument("--envs-total", type=int, default=0,
+                    help="strong scaling: total arms, sharded over the GPUs (--gpus 8 --envs-total 4194304 = "
+                         "BASELINE.json configs[3]; --envs-total 1048576 = the north-star curve)")
     ap.add_argument("--dof", type=int, default=4, choices=(4, 7))
     ap.add_argument("--targets", type=int, default=7)
     ap.add_argument("--episode-len", type=int, default=50)       # test_multi.py:8
+    ap.add_argument("--repeats", type=int, default=0, help="timed regions (0 = enough for >= 50 ms of GPU work, 5..100)")
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x5EED)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
-                    help="collective backend for N > 1: nccl = RCCL over xGMI (default); gloo = CPU rehearsal")
-    ap.add_argument("--single-device", action="store_true",
-                    help="rehearsal only: put every rank on GPU 0 (use with --backend gloo on a 1-GPU box)")
+                    help="torch.distributed backend of the CONTROL plane for N > 1 (barrier, max over ranks, shipping "
+                         "the RCCL unique id); the return gather itself always goes through mt_gather_returns = RCCL, "
+                         "unless --rehearsal")
+    ap.add_argument("--rehearsal", action="store_true",
+                    help="1-GPU box only: every rank on GPU 0, control AND gather over gloo (RCCL refuses two ranks on "
+                         "one device); checks the N > 1 control flow, not a scaling number")
     ap.add_argument("--hw-trig", action="store_true")
     ap.add_argument("--dh-in-lds", action="store_true")
     ap.add_argument("--direct-trig", action="store_true")
@@ -157,83 +302,95 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available() or m.device_count() < 1:
         raise SystemExit("bench.py needs a GPU: the step path has no CPU fallback")
-    dev = 0 if args.single_device else local_rank
+    dev = 0 if args.rehearsal else local_rank
     torch.cuda.set_device(dev)
+    backend = "gloo" if args.rehearsal else args.backend
     if world > 1:
-        if args.backend == "nccl":
+        if backend == "nccl":
             D.init_process_group("nccl")
         else:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             dist.init_process_group(backend="gloo", rank=rank, world_size=world)
 
-    n_local = args.envs_per_gpu
-    n_total = n_local * world                                   # weak scaling: per-GPU work fixed
-    base = rank * n_local
+    strong = args.envs_total > 0
+    if strong:
+        n_total = args.envs_total
+        base, n_local = D.shard_range(n_total, rank, world)
+    else:
+        n_local = args.envs_per_gpu
+        n_total = n_local * world                               # weak scaling: per-GPU work fixed
+        base = rank * n_local
     table = m.REF_DH_TABLE if args.dof == 4 else m.DH7_TABLE
     radius = 51.3 if args.dof == 4 else 92.6
-    eng = m.StepEngine(n_local, args.targets, dh_table=table, radius=radius, device=dev, env_id_base=base,
+    raw = m.StepEngine(n_local, args.targets, dh_table=table, radius=radius, device=dev, env_id_base=base,
                        hw_trig=args.hw_trig, dh_in_lds=args.dh_in_lds, direct_trig=args.direct_trig,
                        specialize=not args.no_specialize, ablate=args.ablate)
-    eng.use_torch_stream()                                      # engine launches and torch/RCCL share one ordering
-    returns = eng.device_tensor(m.lib.F_TOTAL_REWARD)
-    L = args.episode_len
-
-    state = {"step": 0, "episode": 0, "gathered": None}
-    eng.reset_random(args.seed, 0)
-
-    def run_steps(count, kernel_ms=None):
-        """`count` env steps; episode boundary every L steps (gather returns over ranks, reset all)."""
-        done = 0
-        while done < count:
-            seg = min(count - done, L - state["step"] % L)
-            if kernel_ms is not None:
-                eng.lap_begin()             # HIP events on the engine's stream, no host synchronisation
-            if args.fused:
-                eng.rollout_fused(seg, args.seed, state["step"])
-            else:
-                eng.rollout(seg, args.seed, state["step"])
-            if kernel_ms is not None:
-                eng.lap_end()
-                kernel_ms.append(seg)
-            state["step"] += seg
-            done += seg
-            if state["step"] % L == 0:
-                src = returns if args.backend == "nccl" or world == 1 else returns.cpu()
-                state["gathered"] = D.gather_returns(src, n_total)          # RCCL all-gather (identity at N=1)
-                state["episode"] += 1
-                eng.reset_random(args.seed, state["episode"])
+    # The engine keeps its own stream: step launches, the RCCL gather and the resets are all enqueued on it through the
+    # C ABI, in program order; torch only brackets the timed regions (barrier + torch.cuda.synchronize()).
+    if world > 1 and not args.rehearsal:
+        D.connect(raw, rank, world)                             # mt_comm_unique_id -> store -> mt_comm_init (RCCL)
+    elif world > 1:
+        D.attach_gloo_gather(raw, n_total, rank, world)         # rehearsal stand-in for the RCCL gather
+    eng = TimedEngine(raw)
+    L = max(1, min(args.episode_len, args.steps))               # >= 1 gather inside every timed region
+    loop = EpisodeLoop(eng, args.seed, L, fused=args.fused)
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    run_steps(args.warmup)
-    D.gather_returns(returns if args.backend == "nccl" or world == 1 else returns.cpu(), n_total)   # warm-up, untimed
+    # ---- pre-warm: >= PREWARM_S of step launches, so that the timed regions run at the steady clock ------------
+    prewarm = 0
     fence()
-    kernel_ms = []
     t0 = time.perf_counter()
-    run_steps(args.steps, kernel_ms)
-    fence()
-    elapsed = time.perf_counter() - t0
-    laps_ms, _ = eng.laps_total()                     # device time of the step launches inside the timed region
+    while time.perf_counter() - t0 < PREWARM_S:
+        loop.run(max(L, 200))
+        prewarm += max(L, 200)
+        torch.cuda.synchronize()
+    est_s = (time.perf_counter() - t0) / prewarm * args.steps   # one region, estimated
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+        t = torch.tensor([est_s], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        est_s = float(t.item())
+    repeats = args.repeats or int(min(100, max(5, math.ceil(MIN_TIMED_S / max(est_s, 1e-6)))))
+    loop.run(args.warmup)                                       # the W untimed warm-up steps of the contract
+    fence()
+
+    # ---- timed: `repeats` regions of EXACTLY --steps steps, each bracketed by barrier + synchronize -----------
+    regions, kernel_ms, gather_ms, launches, gathers = [], 0.0, 0.0, 0, 0
+    for _ in range(repeats):
+        eng.start_region()
+        fence()
+        t0 = time.perf_counter()
+        ln, gt = loop.run(args.steps, time_kernels=True)
+        fence()
+        regions.append(time.perf_counter() - t0)
+        ms = eng.collect()
+        kernel_ms += ms["step"]
+        gather_ms += ms["gather"]
+        launches += ln
+        gathers += gt
+    regions = np.array(regions)
+    if world > 1:
+        t = torch.tensor(regions, dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)                # a region takes as long as its slowest rank
+        regions = t.cpu().numpy()
+    elapsed = float(np.median(regions))
 
     # sanity on what was computed (not timed): returns are small integers, something happened
-    tr = eng.total_reward()
+    tr = raw.total_reward()
     assert np.isfinite(tr).all() and np.all(tr == np.round(tr))
     if args.ablate:
         print("ABLATION BUILD: timings only, outputs are not the reference's", file=sys.stderr)
-    if state["gathered"] is not None:
-        assert state["gathered"].numel() == n_total
+    assert loop.gathered is not None and loop.gathered.numel() == n_total
+    g = loop.gathered.cpu().numpy()
+    assert np.all(g == np.round(g)) and np.abs(g).max() <= L    # every rank's shard arrived: returns of an L-step episode
 
     if rank == 0:
         bpe = algorithmic_bytes_per_env_step(args.dof, args.targets)
-        launches = sum(kernel_ms)                     # env-steps per env; = launches of step_kernel unless --fused
-        avg_kernel_s = laps_ms / launches / 1e3
+        bpe_actual = actual_bytes_per_env_step(args.dof, args.targets)
+        avg_kernel_s = kernel_ms / launches / 1e3
         achieved = bpe * n_local / avg_kernel_s / 1e9
         trig = 2 if args.hw_trig else (1 if args.direct_trig else 0)
         static = not (args.no_specialize or args.dh_in_lds)
@@ -243,64 +400,74 @@ def main():
                                            ("dh_in_lds", args.dh_in_lds)) if on)
         workload = f"{n_local} arms/GPU x {world} GPU, {args.dof}-DoF DH chain, K={args.targets} targets, " \
                    f"25 sub-steps, random integer-degree actions drawn in-kernel, episode {L} steps"
+        collective = "none (1 GPU: mt_gather_returns is a device copy)"
+        if world > 1:
+            collective = ("gloo all-gather (REHEARSAL on one device, not RCCL)" if args.rehearsal else
+                          "RCCL all-gather of returns per episode through mt_gather_returns (C ABI), straight from the arena")
         out = {
             "metric": METRIC, "value": n_total * args.steps / elapsed, "unit": "env-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
             "config": {"workload": workload, "envs_per_gpu": n_local, "envs_total": n_total, "dof": args.dof,
-                       "targets": args.targets, "substeps": 25, "episode_len": L,
-                       "collective": (f"{'RCCL' if args.backend == 'nccl' else 'gloo (rehearsal)'} all-gather of returns per episode"
-                                      if world > 1 else "none (1 GPU)"),
-                       "kernel_variant": variant},
+                       "targets": args.targets, "substeps": 25, "episode_len": L, "collective": collective,
+                       "kernel_variant": variant, "prewarm_launches": prewarm, "repeats": repeats,
+                       "gathers_in_timed_region": gathers // repeats,
+                       "timing": "median over `repeats` regions of exactly `steps` steps, each bracketed by barrier + "
+                                 "torch.cuda.synchronize(), max over ranks"},
+            "ms_per_step_min": float(regions.min()) / args.steps * 1e3,
+            "ms_per_step_max": float(regions.max()) / args.steps * 1e3,
+            "gather_us": gather_ms * 1e3 / max(1, gathers),
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": load_traffic(f"d{args.dof}_k{args.targets}_n{n_local}"),
+                "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, committed under "
+                                  "profiles/ (traffic.json); not re-measured in this run",
                 "kernel": (f"rollout_kernel<{table_name}> ({L} steps per launch; us per step quoted)" if args.fused else
                            f"step_kernel<{table_name}, sample=true, trig={trig}, lds={str(args.dh_in_lds).lower()}>"),
-                "bytes_per_env_step": bpe, "avg_kernel_us": avg_kernel_s * 1e6,
+                "bytes_per_env_step": bpe, "avg_kernel_us": avg_kernel_s * 1e6, "kernel_launches_timed": launches,
+                "bytes_per_env_step_actual": bpe_actual,
+                "achieved_actual": bpe_actual * n_local / avg_kernel_s / 1e9,
+                "frac_actual": bpe_actual * n_local / avg_kernel_s / 1e9 / HBM_PEAK_GBS,
+                "note": "bytes_per_env_step = SURVEY 8(d) model (counts a 4D-byte action read); the timed kernel draws "
+                        "the action in registers, so *_actual (model - 4D) is what it moves.  At 1 048 576 arms the "
+                        "244 MB working set is about the size of the 256 MiB Infinity Cache: the pure-HBM point is "
+                        "secondary.other_configs['4194304 arms']",
             },
         }
         if world == 1:
             copy_gbs = measured_copy_bandwidth(torch)
             out["roofline"]["measured_copy_gbs"] = copy_gbs
-            out["roofline"]["frac_of_measured_copy"] = achieved / copy_gbs
-        if world == 1 and not args.fused and not args.ablate:
-            # informational, not the headline: the same 50-step episodes as ONE launch each
-            eng.reset_random(args.seed, 0)
-            eng.rollout_fused(L, args.seed, 0)
-            eng.sync()
-            reps = max(1, min(20, args.steps // L))
-            eng.timer_start()
-            for r in range(reps):
-                eng.rollout_fused(L, args.seed, (r + 1) * L)
-            ms = eng.timer_stop()
+            out["roofline"]["frac_actual_of_measured_copy"] = out["roofline"]["achieved_actual"] / copy_gbs
+        secondary = world == 1 and not args.fused and not args.ablate and not args.no_secondary
+        if secondary:
+            # informational, not the headline: the same episodes as ONE launch each
+            us = time_step_launches(m, n_local, table, radius, args.targets, dev, args.seed, fused_len=50, launches=1000)
             out["secondary"] = {"fused_rollout": {
-                "env_steps_per_s": n_local * L * reps / (ms / 1e3), "us_per_step": ms * 1e3 / (L * reps),
-                "steps_per_launch": L, "note": "mt_rollout_fused: state stays in registers/LDS between steps, "
-                "bit-identical results; arithmetic-bound, so the per-step byte model does not apply"}}
-        if world == 1 and not args.fused and not args.ablate and not args.no_cpu_baseline:
-            # informational: BASELINE.json's other single-GPU configurations, same kernel path, short runs
+                "env_steps_per_s": n_local / (us * 1e-6), "us_per_step": us, "steps_per_launch": 50,
+                "note": "mt_rollout_fused: state stays in registers/LDS between steps, bit-identical results; "
+                        "arithmetic-bound, so the per-step byte model does not apply"}}
+            # BASELINE.json's other single-GPU configurations and the pure-HBM point, same kernel path, short runs
             out["secondary"]["other_configs"] = {}
             for label, n2, tbl, rad in (("configs[1]: 65536 arms, 4-DoF", 65536, m.REF_DH_TABLE, 51.3),
+                                        ("131072 arms, 4-DoF (1 M arms over 8 GPUs, per-GPU shard)", 131072, m.REF_DH_TABLE, 51.3),
+                                        ("4194304 arms, 4-DoF (1 GB working set: pure HBM regime)", 4194304, m.REF_DH_TABLE, 51.3),
                                         ("configs[4]: 1048576 arms, 7-DoF table", 1048576, m.DH7_TABLE, 92.6)):
-                e2 = m.StepEngine(n2, args.targets, dh_table=tbl, radius=rad, device=dev)
-                e2.reset_random(args.seed, 0)
-                e2.rollout(200, args.seed, 0)
-                e2.sync()
-                e2.timer_start()
-                e2.rollout(600, args.seed, 200)
-                us = e2.timer_stop() * 1e3 / 600
+                us = time_step_launches(m, n2, tbl, rad, args.targets, dev, args.seed,
+                                        launches=300 if n2 > (1 << 21) else 600)
                 b2 = algorithmic_bytes_per_env_step(len(tbl), args.targets)
+                b2a = actual_bytes_per_env_step(len(tbl), args.targets)
                 out["secondary"]["other_configs"][label] = {
                     "us_per_step": us, "env_steps_per_s": n2 / (us * 1e-6), "bytes_per_env_step": b2,
-                    "frac_of_hbm_peak": b2 * n2 / (us * 1e-6) / 1e9 / HBM_PEAK_GBS}
-                e2.close()
+                    "frac_of_hbm_peak": b2 * n2 / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                    "bytes_per_env_step_actual": b2a,
+                    "frac_actual_of_hbm_peak": b2a * n2 / (us * 1e-6) / 1e9 / HBM_PEAK_GBS}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(table, args.targets)
         print(json.dumps(out), flush=True)
 
-    eng.close()
+    raw.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

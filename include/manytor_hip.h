@@ -235,6 +235,9 @@ MT_API int mt_timer_stop(mt_handle h, float* elapsed_ms);
 MT_API int mt_timer_lap_begin(mt_handle h);
 MT_API int mt_timer_lap_end(mt_handle h);
 MT_API int mt_timer_laps_total(mt_handle h, float* total_ms, int* n_laps);
+/* The same, one figure per lap in recording order (ms[0 .. *n_laps)); clears the laps.  With capacity smaller than the
+ * number of laps it only reports *n_laps and fails, leaving the laps in place. */
+MT_API int mt_timer_lap_times(mt_handle h, float* ms, int capacity, int* n_laps);
 
 /* Stateless kinematics helpers = the module functions of the reference.
  * mt_fk_batch: fk(mode, goals), manytor.py:35-53 -> 4x4 row-major per pose; with

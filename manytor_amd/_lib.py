@@ -111,6 +111,7 @@ PROTOTYPES = {
     "mt_timer_lap_begin": (C.c_int, [_HANDLE]),
     "mt_timer_lap_end": (C.c_int, [_HANDLE]),
     "mt_timer_laps_total": (C.c_int, [_HANDLE, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
+    "mt_timer_lap_times": (C.c_int, [_HANDLE, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_int)]),
     "mt_fk_batch": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_void_p]),
     "mt_route_trace": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "mt_r_theta_batch": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),

@@ -889,6 +889,19 @@ int mt_timer_lap_end(mt_handle h) {
   return lap_record(h);
 }
 
+int mt_timer_lap_times(mt_handle h, float* ms, int capacity, int* n_laps) {
+  MT_REQUIRE(nullptr, h != nullptr, "handle is NULL");
+  MT_REQUIRE(h, n_laps != nullptr && (ms != nullptr || capacity == 0), "NULL argument");
+  if (h->lap_open) return fail(h, MT_ERR_STATE, "mt_timer_lap_times: a lap is still open");
+  const size_t laps = h->laps_used / 2;
+  *n_laps = (int)laps;
+  if ((size_t)capacity < laps) return fail(h, MT_ERR_INVALID_ARG, "mt_timer_lap_times: capacity is smaller than the number of laps");
+  if (laps) MT_HIP(h, hipEventSynchronize(h->lap_events[h->laps_used - 1]));
+  for (size_t i = 0; i < laps; ++i) MT_HIP(h, hipEventElapsedTime(&ms[i], h->lap_events[2 * i], h->lap_events[2 * i + 1]));
+  h->laps_used = 0;
+  return MT_OK;
+}
+
 int mt_timer_laps_total(mt_handle h, float* total_ms, int* n_laps) {
   MT_REQUIRE(nullptr, h != nullptr, "handle is NULL");
   MT_REQUIRE(h, total_ms != nullptr, "total_ms is NULL");

@@ -1,12 +1,16 @@
-"""Env sharding over the GPUs of one node and the per-episode return gather.
+"""Env sharding over the GPUs of one node and the set-up of the per-episode return gather.
 
-The reference has no distributed layer (its "multi-env" is a serial Python loop,
-manytor.py:115-122).  Envs share nothing, so the step path needs no collective:
-rank r owns the contiguous block of global env ids given by ``shard_range`` and
-keys its device RNG with those ids, which makes per-env results independent of
-the number of ranks.  The only exchange is the gather of ``total_reward`` at the
-end of an episode (what test_multi.py:32 prints), done with torch.distributed --
-backend "nccl" is RCCL over xGMI on ROCm, "gloo" on CPU for tests.
+The reference has no distributed layer (its "multi-env" is a serial Python loop, manytor.py:115-122).  Envs share
+nothing, so the step path needs no collective: rank r owns the contiguous block of global env ids given by
+``shard_range`` and keys its device RNG with those ids, which makes per-env results independent of the number of
+ranks.  The only exchange is the gather of ``total_reward`` at the end of an episode (what test_multi.py:32
+prints).  That gather is part of the C ABI (``mt_gather_returns``: RCCL all-gather over xGMI, straight from the arena on
+the engine's stream); this module only does the control plane around it with torch.distributed: process-group
+initialisation from the torchrun environment and shipping the 128-byte RCCL unique id from rank 0 to the others.
+
+``gloo_gather_returns`` is NOT part of the product path: it is the CPU stand-in used by the world-size-2 gloo tests
+and by ``bench.py --rehearsal`` (two ranks on one GPU, which RCCL refuses), to exercise the N > 1 control flow
+where no multi-GPU node is available.
 """
 from __future__ import annotations
 
@@ -47,17 +51,43 @@ def init_process_group(backend=None):
     return rank, local_rank, world
 
 
-def gather_returns(local_returns, n_total: int, group=None, force_collective: bool = False):
-    """All-gather the per-env episode returns of every rank into one (n_total,) tensor in global env order.
+def exchange_unique_id(make_id, rank: int, group=None) -> bytes:
+    """Rank 0 calls `make_id()` (-> 128 bytes naming a new RCCL communicator); every rank returns those bytes.
+    Shipped through the torch.distributed process group (any backend), i.e. the rendezvous torchrun already set up."""
+    import torch.distributed as dist
+    box = [make_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0, group=group)
+    uid = bytes(box[0])
+    if len(uid) != 128:
+        raise RuntimeError(f"unique id has {len(uid)} bytes, expected 128")
+    return uid
 
-    `local_returns`: 1-D tensor of this rank's shard (device tensor with nccl/RCCL, CPU tensor with gloo).
-    Equal shards use one all_gather_into_tensor (a single direct exchange per peer on the xGMI mesh: at
-    4 M envs / 8 GPUs that is 2 MiB per rank); ragged shards are padded to the largest shard first."""
+
+def connect(engine, rank=None, world_size=None, group=None):
+    """Give `engine` (a StepEngine holding this rank's shard) its RCCL communicator: rank 0 creates the unique id
+    (mt_comm_unique_id), it travels through the torch.distributed group, every rank calls mt_comm_init.  Afterwards
+    ``engine.gather_returns()`` all-gathers over xGMI.  Collective: every rank must call it."""
+    import torch.distributed as dist
+
+    from .engine import comm_unique_id
+    if rank is None:
+        rank = dist.get_rank(group)
+    if world_size is None:
+        world_size = dist.get_world_size(group)
+    if world_size == 1:
+        return engine
+    uid = exchange_unique_id(comm_unique_id, rank, group)
+    engine.comm_init(uid, rank, world_size)
+    return engine
+
+
+# ---- CPU stand-in for tests and bench.py --rehearsal (not the product path) --------------------------------------
+def gloo_gather_returns(local_returns, n_total: int, group=None):
+    """All-gather per-env returns (1-D CPU tensor of this rank's shard) into one (n_total,) tensor in global env order
+    with torch.distributed/gloo: same result layout as mt_gather_returns, ragged shards included."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()):
-        return local_returns.clone()
-    if dist.get_world_size(group) == 1 and not force_collective:      # force_collective: exercise RCCL on one rank
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return local_returns.clone()
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
@@ -65,29 +95,28 @@ def gather_returns(local_returns, n_total: int, group=None, force_collective: bo
     if local_returns.numel() != counts[rank]:
         raise ValueError(f"rank {rank} holds {local_returns.numel()} returns, expected {counts[rank]}")
     cmax = max(counts)
-    # stage into torch-owned memory: the source may be a zero-copy view of the engine's arena, which the
-    # collective library has never seen (4 B per env, negligible next to an episode)
-    send = torch.zeros(cmax, dtype=local_returns.dtype, device=local_returns.device)
+    send = torch.zeros(cmax, dtype=local_returns.dtype)
     send[: local_returns.numel()] = local_returns
-    out = torch.empty(world * cmax, dtype=send.dtype, device=send.device)
+    out = torch.empty(world * cmax, dtype=send.dtype)
     dist.all_gather_into_tensor(out, send, group=group)
     if all(c == cmax for c in counts):
         return out
     return torch.cat([out[r * cmax: r * cmax + counts[r]] for r in range(world)])
 
 
-def reduce_return_stats(local_returns, group=None):
-    """(sum, min, max, count) of the returns over all ranks with one all_reduce each -- the cheap alternative
-    when the learner only needs aggregates."""
+def attach_gloo_gather(engine, n_total: int, rank: int, world_size: int, group=None):
+    """bench.py --rehearsal: replace engine.gather_returns by device -> host -> gloo all-gather -> device, so that two
+    ranks sharing one GPU can run the N > 1 control flow.  Never used when real GPUs per rank are available."""
     import torch
-    import torch.distributed as dist
-    s = local_returns.sum(dtype=torch.float64).reshape(1)
-    mn = local_returns.min().reshape(1).to(torch.float64)
-    mx = local_returns.max().reshape(1).to(torch.float64)
-    cnt = torch.tensor([local_returns.numel()], dtype=torch.float64, device=local_returns.device)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(s, group=group)
-        dist.all_reduce(cnt, group=group)
-        dist.all_reduce(mn, op=dist.ReduceOp.MIN, group=group)
-        dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=group)
-    return float(s), float(mn), float(mx), int(cnt)
+
+    def gather_returns(out=None, field=None, row=0):
+        local = torch.from_numpy(engine.total_reward())
+        full = gloo_gather_returns(local, n_total, group)
+        if out is None:
+            out = torch.empty(n_total, dtype=torch.float32, device=f"cuda:{engine.device}")
+        out.copy_(full)
+        return out
+
+    engine.gather_returns = gather_returns
+    engine.total_envs = lambda: n_total
+    return engine

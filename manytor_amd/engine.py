@@ -164,6 +164,18 @@ class StepEngine:
         self._call(self._lib.mt_timer_laps_total, C.byref(ms), C.byref(n))
         return ms.value, n.value
 
+    def lap_times(self):
+        """Device milliseconds of every lap since the last call, in recording order; synchronises once."""
+        cap = 4096
+        while True:
+            buf, n = (C.c_float * cap)(), C.c_int(0)
+            rc = self._lib.mt_timer_lap_times(self._h, buf, cap, C.byref(n))
+            if rc != L.MT_OK and n.value > cap:
+                cap = n.value
+                continue
+            L.check(rc, self._h)
+            return list(buf[: n.value])
+
     # ---- reset --------------------------------------------------------------------------------
     def reset(self, points):
         """Environment.reset (manytor.py:219-253) with caller-supplied targets: (N, K, 3) host array

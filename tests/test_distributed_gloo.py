@@ -1,6 +1,8 @@
-"""world_size-2 gloo rehearsal (CPU) of the N>1 path: shard ranges and the return gather."""
+"""world_size-2 gloo rehearsal (CPU) of the N>1 path: shard ranges, shipping the RCCL unique id through the process
+group, the gather's result layout, and bench.py's episode loop under the driver's own `--steps 20 --warmup 5`."""
 import os
 import socket
+import sys
 
 import numpy as np
 import pytest
@@ -11,6 +13,8 @@ import torch.multiprocessing as mp
 from manytor_amd import distributed as D
 from oracle import philox_ref as px
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 
 def test_shard_ranges_cover_all_envs():
     for n, w in ((1048576, 8), (4194304, 8), (10, 3), (7, 8), (65536, 1)):
@@ -19,6 +23,7 @@ def test_shard_ranges_cover_all_envs():
         for (b0, c0), (b1, _) in zip(spans, spans[1:]):
             assert b0 + c0 == b1
         assert max(c for _, c in spans) - min(c for _, c in spans) <= 1
+    assert D.shard_range(4194304, 3, 8) == (3 * 524288, 524288)      # BASELINE.json configs[3]
 
 
 def _free_port():
@@ -27,41 +32,121 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, n_total, q):
+def _init(rank, world, port):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank))
-    r, _, w = D.init_process_group("gloo")
+    return D.init_process_group("gloo")
+
+
+def _worker(rank, world, port, n_total, q):
+    r, _, w = _init(rank, world, port)
     base, cnt = D.shard_range(n_total, r, w)
     ids = np.arange(base, base + cnt, dtype=np.uint64)
     # each rank derives its shard's inputs from GLOBAL env ids (what the device RNG does)
     local_actions = px.sample_actions(0x5EED, ids, 7, 4)
     local_returns = torch.from_numpy(local_actions.sum(axis=1).astype(np.float32))
-    full = D.gather_returns(local_returns, n_total)
-    stats = D.reduce_return_stats(local_returns)
+    full = D.gloo_gather_returns(local_returns, n_total)
+    # the control plane of D.connect: rank 0 makes the 128-byte id, everybody ends up with the same bytes
+    uid = D.exchange_unique_id(lambda: bytes(range(128)), r)
     if r == 0:
-        q.put((full.numpy(), stats))
+        q.put((full.numpy(), uid))
+    else:
+        assert uid == bytes(range(128))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_total", [4096, 1001])
-def test_gather_returns_world2_gloo(n_total):
+def _spawn(target, args, world=2):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_total, q)) for r in range(2)]
+    procs = [ctx.Process(target=target, args=(r, world, port) + args + (q,)) for r in range(world)]
     for p in procs:
         p.start()
-    full, stats = q.get(timeout=120)
+    out = q.get(timeout=180)
     for p in procs:
-        p.join(timeout=120)
+        p.join(timeout=180)
         assert p.exitcode == 0
+    return out
+
+
+@pytest.mark.parametrize("n_total", [4096, 1001])
+def test_gather_layout_world2_gloo(n_total):
+    full, uid = _spawn(_worker, (n_total,))
     expect = px.sample_actions(0x5EED, np.arange(n_total, dtype=np.uint64), 7, 4).sum(axis=1).astype(np.float32)
     np.testing.assert_array_equal(full, expect)            # shard-invariant: same as one rank owning everything
-    assert stats[3] == n_total and stats[0] == pytest.approx(float(expect.astype(np.float64).sum()))
-    assert stats[1] == expect.min() and stats[2] == expect.max()
+    assert uid == bytes(range(128))
 
 
-def test_gather_returns_single_process_is_identity():
+def test_gather_single_process_is_identity():
     t = torch.arange(10, dtype=torch.float32)
-    assert torch.equal(D.gather_returns(t, 10), t)
+    assert torch.equal(D.gloo_gather_returns(t, 10), t)
+
+
+class _FakeEngine:
+    """Stand-in for StepEngine in bench.EpisodeLoop: returns = number of steps since the last reset + global env id /
+    1e6, gathered over gloo.  Lets the CPU check count what the GPU run would launch."""
+
+    def __init__(self, n_total, rank, world):
+        self.n_total = n_total
+        self.base, self.n = D.shard_range(n_total, rank, world)
+        self.ret = torch.zeros(self.n)
+        self.launches = self.gathers = self.resets = 0
+        self.laps = []
+
+    def reset_random(self, seed, episode):
+        self.ret.zero_()
+        self.resets += 1
+
+    def rollout(self, steps, seed, step0):
+        self.ret += steps
+        self.launches += steps
+
+    rollout_fused = rollout
+
+    def gather_returns(self, out=None):
+        self.gathers += 1
+        ids = torch.arange(self.base, self.base + self.n, dtype=torch.float32)
+        return D.gloo_gather_returns(self.ret + ids / 1e6, self.n_total)
+
+    def lap_begin(self, what):
+        self.laps.append(what)
+
+    def lap_end(self, what):
+        assert self.laps[-1] == what
+
+
+def _bench_loop_worker(rank, world, port, steps, warmup, q):
+    sys.path.insert(0, ROOT)
+    import bench
+    r, _, w = _init(rank, world, port)
+    n_total = 1001
+    eng = _FakeEngine(n_total, r, w)
+    L = max(1, min(50, steps))                            # bench.py: >= 1 gather inside every timed region
+    loop = bench.EpisodeLoop(eng, 0x5EED, L)
+    loop.run(max(L, 200))                                 # pre-warm chunk
+    loop.run(warmup)
+    regions = []
+    for _ in range(3):
+        launches, gathers = loop.run(steps, time_kernels=True)
+        regions.append((launches, gathers))
+        dist.barrier()
+    g = loop.gathered
+    if r == 0:
+        q.put((regions, g.numpy(), eng.launches, eng.gathers, eng.resets, L))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("steps,warmup", [(20, 5), (1000, 50), (7, 0)])
+def test_bench_episode_loop_world2_gloo(steps, warmup):
+    """The driver's invocation `--steps 20 --warmup 5` (and the default, and a tiny one): every timed region launches
+    exactly `steps` steps and contains at least one gather; the gathered vector holds both ranks' shards."""
+    regions, g, launches, gathers, resets, L = _spawn(_bench_loop_worker, (steps, warmup))
+    for ln, gt in regions:
+        assert ln == steps and gt >= 1
+        assert gt in (steps // L, steps // L + 1)
+    assert g.shape == (1001,)
+    ids = np.arange(1001, dtype=np.float32) / np.float32(1e6)
+    np.testing.assert_allclose(g - ids, np.full(1001, L), atol=1e-3)      # a full episode's return from every env
+    assert launches == max(L, 200) + warmup + 3 * steps and resets == gathers + 1
