@@ -84,9 +84,10 @@ def cpu_baseline(dof_table, k, budget_s=12.0, n=65536):
     nc = 1 << 20
     idc = np.arange(nc, dtype=np.uint64)
     cora = c_oracle.COracle(nc, k, table=table, threads=threads)
-    rng = np.random.RandomState(0)
-    pts = rng.uniform(-30, 30, size=(nc, k, 3))
-    pts[..., 2] = np.abs(pts[..., 2])
+    radius = 51.3 if dof == 4 else 92.6
+    # targets: the device stream's law (hemisphere rejection sampling) for 65 536 envs, tiled (the numpy restatement of
+    # the rejection loop is slow at 1 M envs and the step's cost does not depend on which targets it sees)
+    pts = np.tile(px.sample_targets(0x5EED, idc[:n], 0, k, radius).astype(np.float64), (nc // n, 1, 1))
     cora.reset(pts)
     cacts = [px.sample_actions(0x5EED, idc, t, dof).astype(np.float64) for t in range(4)]
     cora.step(cacts[0])
@@ -234,25 +235,18 @@ class TimedEngine:
         return out
 
 
-def time_step_launches(m, n, table, radius, k, dev, seed, fused_len=0, launches=600):
-    """us per step of a secondary configuration: pre-warmed, HIP events around `launches` step launches."""
-    e = m.StepEngine(n, k, dh_table=table, radius=radius, device=dev)
-    e.reset_random(seed, 0)
+def time_step_launches(m, n, table, radius, k, dev, seed, fused=False, steps=600, episode_len=50):
+    """us per step of a secondary configuration: the same episode loop as the headline (reset every `episode_len`
+    steps, so the alive masks stay those of real episodes), pre-warmed, HIP events around the step launches only."""
+    e = TimedEngine(m.StepEngine(n, k, dh_table=table, radius=radius, device=dev))
+    loop = EpisodeLoop(e, seed, episode_len, fused=fused)
     t0 = time.perf_counter()
-    s = 0
     while time.perf_counter() - t0 < 0.15:
-        e.rollout(200, seed, s)
-        s += 200
+        loop.run(4 * episode_len)
         e.sync()
-    e.timer_start()
-    if fused_len:
-        for r in range(max(1, launches // fused_len)):
-            e.rollout_fused(fused_len, seed, s + r * fused_len)
-        steps = max(1, launches // fused_len) * fused_len
-    else:
-        e.rollout(launches, seed, s)
-        steps = launches
-    us = e.timer_stop() * 1e3 / steps
+    e.start_region()
+    launches, _ = loop.run(steps, time_kernels=True)
+    us = e.collect()["step"] * 1e3 / launches
     e.close()
     return us
 
@@ -443,7 +437,7 @@ def main():
         secondary = world == 1 and not args.fused and not args.ablate and not args.no_secondary
         if secondary:
             # informational, not the headline: the same episodes as ONE launch each
-            us = time_step_launches(m, n_local, table, radius, args.targets, dev, args.seed, fused_len=50, launches=1000)
+            us = time_step_launches(m, n_local, table, radius, args.targets, dev, args.seed, fused=True, steps=1000)
             out["secondary"] = {"fused_rollout": {
                 "env_steps_per_s": n_local / (us * 1e-6), "us_per_step": us, "steps_per_launch": 50,
                 "note": "mt_rollout_fused: state stays in registers/LDS between steps, bit-identical results; "
@@ -455,7 +449,7 @@ def main():
                                         ("4194304 arms, 4-DoF (1 GB working set: pure HBM regime)", 4194304, m.REF_DH_TABLE, 51.3),
                                         ("configs[4]: 1048576 arms, 7-DoF table", 1048576, m.DH7_TABLE, 92.6)):
                 us = time_step_launches(m, n2, tbl, rad, args.targets, dev, args.seed,
-                                        launches=300 if n2 > (1 << 21) else 600)
+                                        steps=300 if n2 > (1 << 21) else 600)
                 b2 = algorithmic_bytes_per_env_step(len(tbl), args.targets)
                 b2a = actual_bytes_per_env_step(len(tbl), args.targets)
                 out["secondary"]["other_configs"][label] = {

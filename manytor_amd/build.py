@@ -18,6 +18,18 @@ SOURCES = ["engine.hip", "comm.hip"]
 DEPS = ["engine.hip", "comm.hip", "engine_internal.h", "step_args.h", "kernels.h", "mt_math.h", "philox.h"]
 
 
+EXTRA_FLAGS = [
+    # let x*0 and x+0 fold (static DH tables); staged actions are screened on their bit pattern (unusable_angle), so
+    # no NaN/inf reaches the arithmetic of the step path
+    "-fno-signed-zeros", "-ffinite-math-only",
+    # gfx950 issues v_pk_*_f32 at half the rate of scalar VALU ops, so SLP-packing adjacent fp32 math only adds
+    # register shuffles (measured: sub-step loop 66 -> 43 instructions, 72 -> 58 VGPRs without it)
+    "-fno-slp-vectorize",
+    # FMAs are written out in the source; no implicit contraction, so every kernel rounds a formula identically
+    "-ffp-contract=off",
+]
+
+
 def _hipcc() -> str:
     for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if cand and os.path.exists(cand):
@@ -39,13 +51,7 @@ def build_library(force: bool = False, verbose: bool = False, extra_flags=()) ->
     cmd = [
         _hipcc(), "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-fvisibility=hidden",
         "-I", INCLUDE, "-Wall", "-Wno-unused-function",
-        # let x*0 and x+0 fold (static DH tables); no NaN/inf/-0 is ever produced on the step path
-        "-fno-signed-zeros", "-ffinite-math-only",
-        # gfx950 issues v_pk_*_f32 at half the rate of scalar VALU ops, so SLP-packing adjacent fp32 math only adds
-        # register shuffles (measured: sub-step loop 66 -> 43 instructions, 72 -> 58 VGPRs without it)
-        "-fno-slp-vectorize",
-        # FMAs are written out in the source; no implicit contraction, so every kernel rounds a formula identically
-        "-ffp-contract=off",
+        *EXTRA_FLAGS,
         *extra_flags,
         *[os.path.join(CSRC, s) for s in SOURCES],
         "-o", LIB_PATH + ".tmp",

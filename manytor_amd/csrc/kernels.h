@@ -229,16 +229,99 @@ __device__ __forceinline__ void draw_action(uint64_t seed, uint64_t env_id, uint
 // joint space from `g` (previous pose) to `act`.  Returns the elbow and end-effector positions at the final pose
 // and the minimum z of those two frames over all S poses (ground flag <=> zmin < 0).  Shared by step_kernel and
 // rollout_kernel so both evaluate exactly the same arithmetic.
+// rotate (s, c) of joints 1..D-1 by +delta (SIGN = +1) or -delta (SIGN = -1): the angle-addition step of the recurrence
+template <int D, int SIGN>
+__device__ __forceinline__ void rotate_pose(float (&s)[D], float (&c)[D], const float (&sd)[D], const float (&cd)[D]) {
+#pragma unroll
+  for (int j = 1; j < D; ++j) {
+    const float c2 = __builtin_fmaf(c[j], cd[j], SIGN > 0 ? -(s[j] * sd[j]) : s[j] * sd[j]);
+    s[j] = __builtin_fmaf(s[j], cd[j], SIGN > 0 ? c[j] * sd[j] : -(c[j] * sd[j]));
+    c[j] = c2;
+  }
+}
+
+// sin / cos of the per-sub-step increment.  It is small (|delta| <= 15 degrees for sampled actions at S = 25): when
+// every lane of the wave has |delta| <= 45 the quadrant reduction is skipped.  Both paths give identical bits for
+// such angles (sincos_deg reduces with q = 0), so a lane's result does not depend on its wave-mates.
+template <int D>
+__device__ __forceinline__ void sincos_increment(const float (&st)[D], float (&sd)[D], float (&cd)[D]) {
+  sd[0] = 0.f;
+  cd[0] = 1.f;
+  bool small = true;
+#pragma unroll
+  for (int j = 1; j < D; ++j) small &= fabsf(st[j]) <= 45.0f;
+  if (__all(small)) {
+#pragma unroll
+    for (int j = 1; j < D; ++j) sincos_deg_small(st[j], sd[j], cd[j]);
+  } else {
+#pragma unroll
+    for (int j = 1; j < D; ++j) sincos_deg(st[j], sd[j], cd[j]);
+  }
+}
+
+// The kinematic part of Environment.action (manytor.py:178-192) for one env: S poses on the straight line in
+// joint space from `g` (previous pose) to `act`.  Returns the elbow and end-effector positions at the final pose
+// and the minimum z of those two frames over all S poses (ground flag <=> zmin < 0).  Shared by step_kernel and
+// rollout_kernel so both evaluate exactly the same arithmetic.
+//
+// Two schedules of the recurrence (TRIG == 0), same poses, same arithmetic per pose, hence the same bits (min is
+// order-free):
+//   interleaved (D <= 5): forward and backward half advance in the same loop iteration -- two independent
+//     dependency chains, and 56 VGPRs for the reference arm;
+//   sequential (D >= 6): forward half first, then the action's sincos, the full chain and the backward half.  The two
+//     halves never hold their (s, c) state at the same time: 4 (D - 1) fewer live registers, which is what takes the
+//     7-joint kernel from 97 VGPRs (4 waves/SIMD) to <= 64 (8 waves/SIMD).
 template <class Tbl, int TRIG>
 __device__ __forceinline__ float route_kinematics(const Tbl& t, int S, float inv_sm1, const float (&g)[Tbl::D],
                                                   const float (&act)[Tbl::D], float (&el)[3], float (&e)[3]) {
   constexpr int D = Tbl::D;
+  constexpr bool kSequential = (TRIG == 0 || TRIG == 5) && D >= 6;
   // route[k] = goals + k * (action - goals) / (S-1), route[S-1] = action (np.linspace, manytor.py:182)
   float st[D];
 #pragma unroll
   for (int j = 0; j < D; ++j) st[j] = (act[j] - g[j]) * inv_sm1;
 
   float zmin, zo, ze;
+  if (kSequential) {
+    const int nf = (S - 1) / 2;   // forward poses k = 1..nf
+    const int nb = S - 2 - nf;    // backward poses k = S-2..nf+1   (nb = nf or nf-1)
+    float sd[D], cd[D];
+    sincos_increment<D>(st, sd, cd);
+    {  // k = 0 (the previous pose, manytor.py:182-192 evaluates it again) and the forward half
+      float sF[D], cF[D];
+      sF[0] = 0.f;
+      cF[0] = 1.f;
+#pragma unroll
+      for (int j = 1; j < D; ++j) sincos_deg(g[j] + t.off(j), sF[j], cF[j]);
+      chain_z<Tbl>(sF, cF, t, zo, ze);
+      zmin = fminf(zo, ze);
+      for (int it = 1; it <= nf; ++it) {
+        rotate_pose<D, +1>(sF, cF, sd, cd);
+        chain_z<Tbl>(sF, cF, t, zo, ze);
+        zmin = fminf(zmin, fminf(zo, ze));
+      }
+    }
+    // k = S-1: the action itself, full chain (positions are consumed by the caller), then the backward half
+    float sB[D], cB[D], p[D][3];
+#pragma unroll
+    for (int j = 0; j < D; ++j) sincos_deg(act[j] + t.off(j), sB[j], cB[j]);
+    chain_all<Tbl>(sB, cB, t, p);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      el[q] = (D > 2) ? p[D - 2][q] : 0.f;
+      e[q] = p[D - 1][q];
+    }
+    zmin = fminf(zmin, fminf(el[2], e[2]));
+    sB[0] = 0.f;
+    cB[0] = 1.f;
+    for (int it = 1; it <= nb; ++it) {
+      rotate_pose<D, -1>(sB, cB, sd, cd);
+      chain_z<Tbl>(sB, cB, t, zo, ze);
+      zmin = fminf(zmin, fminf(zo, ze));
+    }
+    return zmin;
+  }
+
   // k = S-1: the action itself, full chain (positions are consumed by the caller)
   float sA[D], cA[D], p[D][3];
 #pragma unroll
@@ -264,21 +347,7 @@ __device__ __forceinline__ float route_kinematics(const Tbl& t, int S, float inv
     // diagnostic builds: no interior sub-steps
   } else if (TRIG == 0 || TRIG == 5) {
     float sd[D], cd[D];
-    sd[0] = 0.f;
-    cd[0] = 1.f;
-    // The per-sub-step increment is small (|delta| <= 15 degrees for sampled actions at S = 25): when every lane of
-    // the wave has |delta| <= 45 the quadrant reduction is skipped.  Both paths give identical bits for such
-    // angles (sincos_deg reduces with q = 0), so a lane's result does not depend on its wave-mates.
-    bool small = true;
-#pragma unroll
-    for (int j = 1; j < D; ++j) small &= fabsf(st[j]) <= 45.0f;
-    if (__all(small)) {
-#pragma unroll
-      for (int j = 1; j < D; ++j) sincos_deg_small(st[j], sd[j], cd[j]);
-    } else {
-#pragma unroll
-      for (int j = 1; j < D; ++j) sincos_deg(st[j], sd[j], cd[j]);
-    }
+    sincos_increment<D>(st, sd, cd);
     float sB[D], cB[D];
 #pragma unroll
     for (int j = 0; j < D; ++j) {
@@ -291,21 +360,11 @@ __device__ __forceinline__ float route_kinematics(const Tbl& t, int S, float inv
     const int nb = S - 2 - nf;    // backward poses k = S-2..nf+1   (nb = nf or nf-1)
 #pragma unroll 2
     for (int it = 1; it <= nf; ++it) {
-#pragma unroll
-      for (int j = 1; j < D; ++j) {  // rotate by +delta
-        const float c2 = __builtin_fmaf(cF[j], cd[j], -(sF[j] * sd[j]));
-        sF[j] = __builtin_fmaf(sF[j], cd[j], cF[j] * sd[j]);
-        cF[j] = c2;
-      }
+      rotate_pose<D, +1>(sF, cF, sd, cd);
       chain_z<Tbl>(sF, cF, t, zo, ze);
       zmin = fminf(zmin, fminf(zo, ze));
       if (it <= nb) {
-#pragma unroll
-        for (int j = 1; j < D; ++j) {  // rotate by -delta
-          const float c2 = __builtin_fmaf(cB[j], cd[j], sB[j] * sd[j]);
-          sB[j] = __builtin_fmaf(sB[j], cd[j], -(cB[j] * sd[j]));
-          cB[j] = c2;
-        }
+        rotate_pose<D, -1>(sB, cB, sd, cd);
         chain_z<Tbl>(sB, cB, t, zo, ze);
         zmin = fminf(zmin, fminf(zo, ze));
       }

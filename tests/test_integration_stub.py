@@ -6,6 +6,8 @@ import re
 import numpy as np
 import pytest
 
+from parity_util import assert_obs_close
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -22,6 +24,7 @@ def test_integration_md_stub_runs(golden):
     for t in range(3):
         obs2, reward, done = me.step([list(a) for a in g["action"][t]])
         assert len(obs2) == 6 and obs2[0].shape == (21,) and obs2[0].dtype == np.float64
-        np.testing.assert_allclose(np.array(obs2)[:, 0::3], g["obs2"][t][:, 0::3], atol=2e-4)
+        alive_before = g["alives"][t - 1] if t else np.ones((6, 7), dtype=bool)
+        assert_obs_close(np.array(obs2), g["obs2"][t], g["jc"][t][:, 2], g["points"][0], alive_before)
         assert reward == [int(v) for v in g["reward"][t]]
         assert done == [bool(v) for v in g["done"][t]]
