@@ -31,17 +31,30 @@ namespace mt {
 // Row access: every SoA row is addressed as (wave-uniform row base) + (32-bit per-lane BYTE offset), which maps
 // onto the `global_load/store v, v_off, s[base:base+1]` form -- the row base stays in SGPRs and no 64-bit
 // per-lane address arithmetic is needed.  Byte offsets fit 32 bits because mt_create caps n_envs below 2^30.
+// The row base MUST be the same in every lane.  It is passed through readfirstlane (free on a value that already
+// sits in SGPRs): without that the optimiser folds `base + row * ld` and the lane offset into one per-lane 64-bit
+// address per row and keeps all of them in VGPRs for the whole kernel (14 registers for 7 joint rows plus 64-bit
+// VALU adds; measured: step_kernel<Dh7Table> 86 -> VGPRs, see profiles/r02_kernel_resources.txt).
+template <typename T>
+using global_ptr = __attribute__((address_space(1))) T*;  // a pointer known to be global memory: global_*, not flat_*
+
+__device__ __forceinline__ global_ptr<char> uniform_row(const void* row) {
+  const uint64_t v = reinterpret_cast<uint64_t>(row);
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+  const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  return (global_ptr<char>)(((uint64_t)hi << 32) | lo);
+}
 template <typename T>
 __device__ __forceinline__ T ldr(const T* row, uint32_t boff) {
-  return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(row) + boff);
+  return *(global_ptr<const T>)(uniform_row(row) + boff);
 }
 template <typename T>
 __device__ __forceinline__ void str(T* row, uint32_t boff, T v) {
-  *reinterpret_cast<T*>(reinterpret_cast<char*>(row) + boff) = v;
+  *(global_ptr<T>)(uniform_row(row) + boff) = v;
 }
 template <typename T>
 __device__ __forceinline__ void str_stream(T* row, uint32_t boff, T v) {
-  T* p = reinterpret_cast<T*>(reinterpret_cast<char*>(row) + boff);
+  global_ptr<T> p = (global_ptr<T>)(uniform_row(row) + boff);
 #if MT_NT_STORES
   __builtin_nontemporal_store(v, p);
 #else
@@ -229,11 +242,25 @@ __device__ __forceinline__ void draw_action(uint64_t seed, uint64_t env_id, uint
 // joint space from `g` (previous pose) to `act`.  Returns the elbow and end-effector positions at the final pose
 // and the minimum z of those two frames over all S poses (ground flag <=> zmin < 0).  Shared by step_kernel and
 // rollout_kernel so both evaluate exactly the same arithmetic.
-// rotate (s, c) of joints 1..D-1 by +delta (SIGN = +1) or -delta (SIGN = -1): the angle-addition step of the recurrence
-template <int D, int SIGN>
+// Joints whose angle can influence the z of the last two frames (what chain_z computes).  Joint 0 never does (handled
+// by the callers: index 0 is skipped everywhere); the LAST joint does only through a(D-1) * X'.z, so for a static
+// table whose last row has a = 0 (the 7-joint table: a pure d offset along the previous z) its sine / cosine are never
+// needed at the interior sub-steps.  The compiler does not discover this by itself (the rotation is a loop-carried
+// cycle): 6 of 57 instructions of the 7-joint sub-step loop.
+template <class Tbl>
+struct ZJoints {
+  static constexpr int value = (Tbl::a(Tbl::D - 1) == 0.f) ? Tbl::D - 1 : Tbl::D;
+};
+template <int D>
+struct ZJoints<RtTable<D>> {
+  static constexpr int value = D;
+};
+
+// rotate (s, c) of joints 1..JN-1 by +delta (SIGN = +1) or -delta (SIGN = -1): the angle-addition step of the recurrence
+template <int D, int JN, int SIGN>
 __device__ __forceinline__ void rotate_pose(float (&s)[D], float (&c)[D], const float (&sd)[D], const float (&cd)[D]) {
 #pragma unroll
-  for (int j = 1; j < D; ++j) {
+  for (int j = 1; j < JN; ++j) {
     const float c2 = __builtin_fmaf(c[j], cd[j], SIGN > 0 ? -(s[j] * sd[j]) : s[j] * sd[j]);
     s[j] = __builtin_fmaf(s[j], cd[j], SIGN > 0 ? c[j] * sd[j] : -(c[j] * sd[j]));
     c[j] = c2;
@@ -243,19 +270,22 @@ __device__ __forceinline__ void rotate_pose(float (&s)[D], float (&c)[D], const 
 // sin / cos of the per-sub-step increment.  It is small (|delta| <= 15 degrees for sampled actions at S = 25): when
 // every lane of the wave has |delta| <= 45 the quadrant reduction is skipped.  Both paths give identical bits for
 // such angles (sincos_deg reduces with q = 0), so a lane's result does not depend on its wave-mates.
-template <int D>
+template <int D, int JN>
 __device__ __forceinline__ void sincos_increment(const float (&st)[D], float (&sd)[D], float (&cd)[D]) {
-  sd[0] = 0.f;
-  cd[0] = 1.f;
+#pragma unroll
+  for (int j = 0; j < D; ++j) {
+    sd[j] = 0.f;
+    cd[j] = 1.f;
+  }
   bool small = true;
 #pragma unroll
-  for (int j = 1; j < D; ++j) small &= fabsf(st[j]) <= 45.0f;
+  for (int j = 1; j < JN; ++j) small &= fabsf(st[j]) <= 45.0f;
   if (__all(small)) {
 #pragma unroll
-    for (int j = 1; j < D; ++j) sincos_deg_small(st[j], sd[j], cd[j]);
+    for (int j = 1; j < JN; ++j) sincos_deg_small(st[j], sd[j], cd[j]);
   } else {
 #pragma unroll
-    for (int j = 1; j < D; ++j) sincos_deg(st[j], sd[j], cd[j]);
+    for (int j = 1; j < JN; ++j) sincos_deg(st[j], sd[j], cd[j]);
   }
 }
 
@@ -275,6 +305,7 @@ template <class Tbl, int TRIG>
 __device__ __forceinline__ float route_kinematics(const Tbl& t, int S, float inv_sm1, const float (&g)[Tbl::D],
                                                   const float (&act)[Tbl::D], float (&el)[3], float (&e)[3]) {
   constexpr int D = Tbl::D;
+  constexpr int JN = ZJoints<Tbl>::value;
   constexpr bool kSequential = (TRIG == 0 || TRIG == 5) && D >= 6;
   // route[k] = goals + k * (action - goals) / (S-1), route[S-1] = action (np.linspace, manytor.py:182)
   float st[D];
@@ -286,17 +317,21 @@ __device__ __forceinline__ float route_kinematics(const Tbl& t, int S, float inv
     const int nf = (S - 1) / 2;   // forward poses k = 1..nf
     const int nb = S - 2 - nf;    // backward poses k = S-2..nf+1   (nb = nf or nf-1)
     float sd[D], cd[D];
-    sincos_increment<D>(st, sd, cd);
+    sincos_increment<D, JN>(st, sd, cd);
     {  // k = 0 (the previous pose, manytor.py:182-192 evaluates it again) and the forward half
       float sF[D], cF[D];
-      sF[0] = 0.f;
-      cF[0] = 1.f;
 #pragma unroll
-      for (int j = 1; j < D; ++j) sincos_deg(g[j] + t.off(j), sF[j], cF[j]);
+      for (int j = 0; j < D; ++j) {
+        sF[j] = 0.f;
+        cF[j] = 1.f;
+      }
+#pragma unroll
+      for (int j = 1; j < JN; ++j) sincos_deg(g[j] + t.off(j), sF[j], cF[j]);
       chain_z<Tbl>(sF, cF, t, zo, ze);
       zmin = fminf(zo, ze);
+#pragma unroll 2
       for (int it = 1; it <= nf; ++it) {
-        rotate_pose<D, +1>(sF, cF, sd, cd);
+        rotate_pose<D, JN, +1>(sF, cF, sd, cd);
         chain_z<Tbl>(sF, cF, t, zo, ze);
         zmin = fminf(zmin, fminf(zo, ze));
       }
@@ -314,8 +349,9 @@ __device__ __forceinline__ float route_kinematics(const Tbl& t, int S, float inv
     zmin = fminf(zmin, fminf(el[2], e[2]));
     sB[0] = 0.f;
     cB[0] = 1.f;
+#pragma unroll 2
     for (int it = 1; it <= nb; ++it) {
-      rotate_pose<D, -1>(sB, cB, sd, cd);
+      rotate_pose<D, JN, -1>(sB, cB, sd, cd);
       chain_z<Tbl>(sB, cB, t, zo, ze);
       zmin = fminf(zmin, fminf(zo, ze));
     }
@@ -336,10 +372,13 @@ __device__ __forceinline__ float route_kinematics(const Tbl& t, int S, float inv
 
   // k = 0: the previous pose (manytor.py:182-192 evaluates it again: a pose left below ground costs -1 twice)
   float sF[D], cF[D];
-  sF[0] = 0.f;
-  cF[0] = 1.f;
 #pragma unroll
-  for (int j = 1; j < D; ++j) sincos_deg(g[j] + t.off(j), sF[j], cF[j]);
+  for (int j = 0; j < D; ++j) {
+    sF[j] = 0.f;
+    cF[j] = 1.f;
+  }
+#pragma unroll
+  for (int j = 1; j < JN; ++j) sincos_deg(g[j] + t.off(j), sF[j], cF[j]);
   chain_z<Tbl>(sF, cF, t, zo, ze);
   zmin = fminf(zmin, fminf(zo, ze));
 
@@ -347,7 +386,7 @@ __device__ __forceinline__ float route_kinematics(const Tbl& t, int S, float inv
     // diagnostic builds: no interior sub-steps
   } else if (TRIG == 0 || TRIG == 5) {
     float sd[D], cd[D];
-    sincos_increment<D>(st, sd, cd);
+    sincos_increment<D, JN>(st, sd, cd);
     float sB[D], cB[D];
 #pragma unroll
     for (int j = 0; j < D; ++j) {
@@ -360,11 +399,11 @@ __device__ __forceinline__ float route_kinematics(const Tbl& t, int S, float inv
     const int nb = S - 2 - nf;    // backward poses k = S-2..nf+1   (nb = nf or nf-1)
 #pragma unroll 2
     for (int it = 1; it <= nf; ++it) {
-      rotate_pose<D, +1>(sF, cF, sd, cd);
+      rotate_pose<D, JN, +1>(sF, cF, sd, cd);
       chain_z<Tbl>(sF, cF, t, zo, ze);
       zmin = fminf(zmin, fminf(zo, ze));
       if (it <= nb) {
-        rotate_pose<D, -1>(sB, cB, sd, cd);
+        rotate_pose<D, JN, -1>(sB, cB, sd, cd);
         chain_z<Tbl>(sB, cB, t, zo, ze);
         zmin = fminf(zmin, fminf(zo, ze));
       }
@@ -376,7 +415,7 @@ __device__ __forceinline__ float route_kinematics(const Tbl& t, int S, float inv
     for (int k = 1; k < S - 1; ++k) {
       const float fk = (float)k;
 #pragma unroll
-      for (int j = 1; j < D; ++j) {
+      for (int j = 1; j < JN; ++j) {
         const float pose = __builtin_fmaf(fk, st[j], gq[j]);
         if (TRIG == 2)
           sincos_deg_hw(pose, sF[j], cF[j]);
@@ -394,7 +433,8 @@ __device__ __forceinline__ float route_kinematics(const Tbl& t, int S, float inv
 // (slot = number of episodes it finished before, modulo the ring size) and in the one-slot last_return row.
 __device__ __forceinline__ void record_finished(const StepArgs& a, uint32_t i, uint32_t episode, float ret) {
   str(a.last_return, i * 4u, ret);
-  if (a.ring_slots) str(a.ring + (int64_t)((episode - a.episode0) % a.ring_slots) * a.ld, i * 4u, ret);
+  if (a.ring_slots)  // the slot differs from lane to lane: plain per-lane addressing, not a uniform row
+    a.ring[(int64_t)((episode - a.episode0) % a.ring_slots) * a.ld + i] = ret;
 }
 
 // Staged actions come from outside (a policy, a host array): anything that is not a finite angle of at most
@@ -402,8 +442,13 @@ __device__ __forceinline__ void record_finished(const StepArgs& a, uint32_t i, u
 // so the check survives -ffinite-math-only.
 __device__ __forceinline__ bool unusable_angle(float v) { return (__float_as_uint(v) & 0x7FFFFFFFu) > 0x47000000u; }
 
+// Asking for 8 waves per SIMD (= 64 VGPRs) only where the default recurrence kernel is within reach of it: the
+// 7-joint table lands on 68 without the request and fits 64 with it, no scratch (profiles/r02_kernel_resources.txt).
+template <class Tbl, int TRIG>
+constexpr int step_min_waves() { return (TRIG == 0 && Tbl::D >= 6 && Tbl::D <= 7) ? 8 : 1; }
+
 template <class Tbl, bool SAMPLE, int TRIG, bool LDS>
-__global__ __launch_bounds__(kBlock) void step_kernel(const StepArgs a) {
+__global__ __launch_bounds__(kBlock, (step_min_waves<Tbl, TRIG>())) void step_kernel(const StepArgs a) {
   constexpr int D = Tbl::D;
   __shared__ DhConst sh;
   if (LDS) {
@@ -418,13 +463,20 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const StepArgs a) {
   if (i >= a.n) return;
   const int64_t ld = a.ld;
 
+  // Long arms (D >= 6) are register-bound: their kernel keeps nothing alive across the sub-step loops that it can
+  // fetch or store on the other side of them (alive mask and return loaded after, new goals stored before).
+  constexpr bool kLean = D >= 6;
   float g[D], act[D];
 #pragma unroll
   for (int j = 0; j < D; ++j) g[j] = ldr(a.goals + j * ld, i * 4u);
   // The alive mask and the return are requested now, ahead of the arithmetic that does not need them.
   // (Requesting the target rows here as well was measured: no gain, -2 waves/SIMD -- profiles/r01_variants.md.)
-  const uint32_t am = ldr(a.alive, i * 4u);
-  const float total_in = ldr(a.total_reward, i * 4u);
+  uint32_t am = 0;
+  float total_in = 0.f;
+  if (!kLean) {
+    am = ldr(a.alive, i * 4u);
+    total_in = ldr(a.total_reward, i * 4u);
+  }
   if (SAMPLE) {
     // not stored separately: the action taken becomes `goals` below (manytor.py:184), 4D bytes of traffic saved
     draw_action<D>(((uint64_t)a.seed_hi << 32) | a.seed_lo, (uint64_t)(a.env_base + i), a.major, act);
@@ -441,10 +493,18 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const StepArgs a) {
       atomicAdd(a.bad_actions, 1u);
     }
   }
+  if (kLean) {  // goals = action (manytor.py:184): the old pose is in registers already
+#pragma unroll
+    for (int j = 0; j < D; ++j) str(a.goals + j * ld, i * 4u, act[j]);
+  }
 
   float el[3], e[3];
   const float zmin = route_kinematics<Tbl, TRIG>(t, a.S, a.inv_sm1, g, act, el, e);
   const bool ground = zmin < 0.f;  // manytor.py:191
+  if (kLean) {
+    am = ldr(a.alive, i * 4u);
+    total_in = ldr(a.total_reward, i * 4u);
+  }
 
   // obs2 (before pickup, manytor.py:204) and pickup (manytor.py:206) per target
   uint32_t nam = am;
@@ -465,8 +525,10 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const StepArgs a) {
   bool done = (nam == 0u);                                    // manytor.py:170-171
   if (a.flags & MT_FLAG_TERMINATE_ON_GROUND) done |= ground;
 
+  if (!kLean) {
 #pragma unroll
-  for (int j = 0; j < D; ++j) str(a.goals + j * ld, i * 4u, act[j]);
+    for (int j = 0; j < D; ++j) str(a.goals + j * ld, i * 4u, act[j]);
+  }
 #pragma unroll
   for (int q = 0; q < 3; ++q) str_stream(a.ee + q * ld, i * 4u, e[q]);
   str(a.alive, i * 4u, nam);
