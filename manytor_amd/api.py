@@ -185,7 +185,6 @@ class Multienv:
             raise ValueError("rng must be 'numpy' or 'device'")
         self._viewer = ViewerLink(*viewer) if isinstance(viewer, (tuple, list)) else viewer
         self._view_envs = int(view_envs)
-        self._fresh = True
         self._dh_table = dh_table
         self._substeps = substeps
         self.env_shape = env_shape
@@ -233,8 +232,7 @@ class Multienv:
         goals = self._cached(L.F_GOALS)[:m]
         traces = route_trace(prev_goals[:m], goals, dh_table=self._dh_table, substeps=self._substeps,
                              device=self._engine.device)
-        self._viewer.frames(list(range(m)), traces, self._cached(L.F_POINTS)[:m], first=self._fresh)
-        self._fresh = False
+        self._viewer.frames(list(range(m)), traces, self._cached(L.F_POINTS)[:m], first=False)
 
     def reset(self, returnable=False):
         """manytor.py:106-109."""
@@ -243,7 +241,6 @@ class Multienv:
         else:
             self._engine.reset_random(self.seed, self._episode)
         self._episode += 1
-        self._fresh = True
         if self.rendering and self._viewer is not None:
             self._viewer.clear()                       # manytor.py:246-249
         if returnable:
@@ -315,7 +312,6 @@ class Environment:
         self._keep_trajectory = bool(keep_trajectory)
         self._dh_table = dh_table
         self._substeps = substeps
-        self._fresh = True
         # manytor.py:135: end-effector trace, one row per sub-step, seeded with (0, 0, 51.3).  Kept lazily: a step only
         # notes its (previous pose, action) pair; the rows are computed -- one mt_route_trace call for all pending
         # steps -- when `trajectory` is read.
@@ -392,8 +388,7 @@ class Environment:
                                        np.asarray(action, dtype=np.float32).reshape(1, -1)))
         if streaming:
             trace = route_trace(prev, action, dh_table=self._dh_table, substeps=self._substeps, device=self._engine.device)
-            self._viewer.frames([self.id], trace, self._engine.points(), first=self._fresh)
-            self._fresh = False
+            self._viewer.frames([self.id], trace, self._engine.points(), first=False)
 
     def action(self, action, obs=None):
         """manytor.py:175-213 -> (reward, obs2).  Like the reference it does not add to total_reward;
@@ -423,7 +418,6 @@ class Environment:
         self._episode += 1
         self._pose = np.zeros_like(self._pose)
         self.trajectory = np.array([0.0, 0.0, 51.3])      # manytor.py:223 (drops pending rows)
-        self._fresh = True
         if self.rendering and self._viewer is not None:
             self._viewer.clear()                           # manytor.py:246-249
         if returnable:

@@ -12,8 +12,13 @@ Datagrams (JSON lists, NaN spelled the way Python's json does):
   stop   [NaN, NaN, 2]                                  (manytor.py:277; Multienv's own stop sends raw bytes, :100 --
                                                          an upstream bug the viewer cannot parse; the JSON form is used)
   clear  [NaN, NaN, 4]                                  trajectory reset (manytor.py:247)
-  frame  [id, NaN, flag,  jc(4x3)...,  points(Kx3)...,  ee(3)]  flattened (manytor.py:197-200); flag 1 = first frame
-         after a reset (the viewer then restarts the trajectory at (0, 0, 51.3), plotting.py:84)
+  frame  [id, NaN, flag,  jc(4x3)...,  points(Kx3)...,  ee(3)]  flattened (manytor.py:197-200).  The viewer restarts a
+         trajectory when flag == 1 (plotting.py:84), but the reference itself never sends 1: it tests
+         `trajectory.size == 3` AFTER appending the sub-step's row (manytor.py:190,196), so every frame it emits
+         carries 0 (fixture F9, captured from the reference) and trajectories restart only on `clear`.  The drop-in
+         classes do the same; `first=True` remains available to callers who want the viewer's restart.
+
+Pinned by tests/golden/f9_viewer_frames.npz: the datagrams a reference Environment emitted for two steps.
 """
 from __future__ import annotations
 

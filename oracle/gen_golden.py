@@ -9,7 +9,8 @@ the GPU box):
 It imports /root/reference/manytor.py unmodified, seeds numpy's global RNG,
 drives the reference's own functions/classes with rendering off, and stores
 inputs + outputs as small .npz files (pure data: no reference source text).
-Fixture ids follow SURVEY.md section 8(c): F1..F7, plus F8 (dh / r_theta KATs).
+Fixture ids follow SURVEY.md section 8(c): F1..F7, plus F8 (dh / r_theta KATs) and F9 (the viewer datagrams the
+reference emits while stepping, captured without starting its viewer).
 """
 import os
 import sys
@@ -265,7 +266,44 @@ def gen_f8(m=64):
     save("f8_dh_rtheta_kat", dh_params=params, dh_matrices=dh_mats, v1=v1, v2=v2, r_theta=rt)
 
 
+# ------------------------------------------------------------- F9 viewer datagrams
+class _Capture:
+    """Stands in for the UDP socket of a rendering Environment (manytor.py:265-267): keeps what would be sent."""
+
+    def __init__(self):
+        self.msgs = []
+
+    def sendto(self, msg, dest):
+        self.msgs.append(bytes(msg))
+
+
+def gen_f9(seed=9, k=7, steps=2):
+    """The frames manytor.py:194-201 sends per sub-step and the clear message of :246-249, as parsed numbers.
+    render() itself is never called (it would spawn the vispy viewer): only the flag and the socket are set."""
+    import json
+    np.random.seed(seed)
+    env = tor.Environment(k, index=3)
+    env.reset()
+    cap = _Capture()
+    env.rendering, env.udp, env.dest = True, cap, None
+    actions, frames = [], []
+    for _ in range(steps):
+        a = env.action_sample()
+        env.step(a)
+        actions.append(np.array(a, dtype=np.int64))
+    frames = np.array([json.loads(m) for m in cap.msgs], dtype=np.float64)     # (steps*25, 3*(1+4+K+1)); NaN kept
+    lengths = np.array([len(m) for m in cap.msgs], dtype=np.int64)
+    points = env.points.copy()
+    cap.msgs = []
+    env.reset()                                                                  # rendering: sends [nan, nan, 4]
+    clear = np.array(json.loads(cap.msgs[0]), dtype=np.float64)
+    assert len(cap.msgs) == 1 and frames.shape == (steps * 25, 3 * (1 + 4 + k + 1))
+    save("f9_viewer_frames", seed=np.int64(seed), obj_number=np.int64(k), env_id=np.int64(3), action=np.array(actions),
+         frames=frames, datagram_bytes=lengths, points=points, clear=clear)
+
+
 if __name__ == "__main__":
+    gen_f9()
     gen_f1()
     gen_f2()
     gen_f3()

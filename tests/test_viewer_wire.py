@@ -5,6 +5,7 @@ import math
 import socket
 
 import numpy as np
+import pytest
 
 from manytor_amd import viewer as V
 
@@ -67,4 +68,56 @@ def test_link_sends_datagrams_in_lockstep_order():
     assert json.loads(got[-2])[2] == 4 and json.loads(got[-1])[2] == 2
     assert link.sent == len(got)
     link.close()
+    recv.close()
+
+
+def test_f9_reference_datagrams_pin_the_frame_format(golden):
+    """Fixture F9 = the datagrams a reference Environment(7, index=3) sent over two steps (captured by giving it a
+    socket stand-in, manytor.py:194-201) and on the following reset (:246-249).  encode_frame fed with the pieces of a
+    reference frame must give back the same numbers in the same order, and fit the viewer's 1024-byte read."""
+    g = golden("f9_viewer_frames")
+    k, env_id = int(g["obj_number"]), int(g["env_id"])
+    frames = g["frames"]
+    assert frames.shape == (2 * 25, 3 * (1 + 4 + k + 1))
+    for f in frames:
+        rows = f.reshape(-1, 3)
+        assert int(rows[0, 0]) == env_id and math.isnan(rows[0, 1]) and rows[0, 2] == 0     # the reference never sends 1
+        mine = np.array(json.loads(V.encode_frame(env_id, rows[1:5], rows[5:5 + k], rows[-1])), dtype=np.float64)
+        assert mine.shape == f.shape
+        assert int(mine[0]) == env_id and math.isnan(mine[1]) and mine[2] == 0
+        np.testing.assert_allclose(mine[3:], f[3:], atol=1e-4)
+        np.testing.assert_array_equal(rows[-1], rows[4])          # last row = the end effector = joints_coordinates[3]
+    assert g["datagram_bytes"].max() <= V.MAX_DATAGRAM
+    clear = np.array(json.loads(V.encode_clear()), dtype=np.float64)
+    np.testing.assert_array_equal(np.isnan(clear), np.isnan(g["clear"]))
+    assert clear[2] == g["clear"][2] == 4
+
+
+@pytest.mark.gpu
+def test_f9_environment_streams_the_reference_frames(golden):
+    """The same two steps through the drop-in Environment with a viewer link: 50 datagrams, each within 1e-4 of the
+    reference's (positions from the GPU's route trace), then the clear message on reset."""
+    import manytor_amd as m
+    g = golden("f9_viewer_frames")
+    k, env_id = int(g["obj_number"]), int(g["env_id"])
+    recv = socket.socket(socket.AF_INET, socket.SOCK_DGRAM)
+    recv.setsockopt(socket.SOL_SOCKET, socket.SO_RCVBUF, 1 << 22)
+    recv.bind(("127.0.0.1", 0))
+    recv.settimeout(5.0)
+    np.random.seed(int(g["seed"]))
+    env = m.Environment(k, index=env_id, viewer=("127.0.0.1", recv.getsockname()[1]))
+    env.reset()
+    env.render()                                       # init datagram [1, K, 3] (manytor.py:271)
+    for a in g["action"]:
+        assert list(env.action_sample()) == list(a)     # same R2 stream as the reference
+        env.step(list(a))
+    env.reset()
+    got = [recv.recvfrom(2048)[0] for _ in range(1 + 50 + 1)]
+    assert json.loads(got[0]) == [1, k, 3]
+    for data, ref in zip(got[1:51], g["frames"]):
+        mine = np.array(json.loads(data), dtype=np.float64)
+        assert int(mine[0]) == env_id and math.isnan(mine[1]) and mine[2] == ref[2] == 0
+        np.testing.assert_allclose(mine[3:], ref[3:], atol=2e-4)
+    last = json.loads(got[51])
+    assert math.isnan(last[0]) and last[2] == 4
     recv.close()

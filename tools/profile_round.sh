@@ -1,0 +1,14 @@
+#!/bin/bash
+# Round profile: kernel trace + stats of the driver's own bench command, then the PMC passes (separate runs).
+# usage: tools/profile_round.sh <tag>      -> gpurun_out/prof_<tag>/...
+set -e
+tag=$1
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+out=gpurun_out/prof_$tag
+mkdir -p "$out"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > "$out/bench_under_trace.json" 2> "$out/trace.err"
+find "$out/trace" -name "*kernel_stats.csv" -exec cp {} "$out/kernel_stats.csv" \;
+head -12 "$out/kernel_stats.csv"
+bash tools/pmc_step.sh "$out/pmc_d4" --no-secondary > "$out/pmc_d4.log" 2>&1 || echo "pmc d4 failed"
+bash tools/pmc_step.sh "$out/pmc_d7" --no-secondary --dof 7 > "$out/pmc_d7.log" 2>&1 || echo "pmc d7 failed"
+tail -12 "$out/pmc_d4.log"; tail -12 "$out/pmc_d7.log"
