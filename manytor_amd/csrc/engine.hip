@@ -99,6 +99,13 @@ void launch_step_t(mt_handle h, const StepArgs& args, bool sample) {
     }
     return;
   }
+  if (h->trig == 0 && h->prefetch) {  // small batches: target loads in flight before the kinematics (kernels.h, PF)
+    if (sample)
+      hipLaunchKernelGGL((step_kernel<Tbl, true, 0, false, kPrefetch>), g, b, 0, h->stream, args);
+    else
+      hipLaunchKernelGGL((step_kernel<Tbl, false, 0, false, kPrefetch>), g, b, 0, h->stream, args);
+    return;
+  }
   switch (h->trig) {
     case 1: if (sample) MT_LAUNCH_STEP(true, 1, false); else MT_LAUNCH_STEP(false, 1, false); break;
     case 2: if (sample) MT_LAUNCH_STEP(true, 2, false); else MT_LAUNCH_STEP(false, 2, false); break;
@@ -312,6 +319,11 @@ int mt_create(mt_handle* out, const mt_config* cfg) {
   if (cfg->flags & MT_FLAG_ABLATE_LOOP) h->trig = (cfg->flags & MT_FLAG_ABLATE_OBS) ? 4 : 3;
   else if (cfg->flags & MT_FLAG_ABLATE_OBS) h->trig = 5;   /* OBS alone = arithmetic-only build */
   h->lds_table = (cfg->flags & MT_FLAG_DH_IN_LDS) != 0;
+  // Latency variant of the step kernel for batches that leave the chip under-occupied (<= 2 waves per SIMD: measured
+  // 7.08 -> 6.43 us at 65 536 arms, 7.86 -> 7.14 at 131 072, but 14.7 -> 15.2 at 262 144; profiles/r02_variants.md section 3);
+  // the streaming variant everywhere else.  MT_PREFETCH=0/1 overrides the choice for experiments.
+  h->prefetch = cfg->n_envs <= 131072;
+  if (const char* env = std::getenv("MT_PREFETCH")) h->prefetch = std::atoi(env) != 0;
 
   auto bail = [&](int code, const std::string& msg) {
     g_last_error = msg;

@@ -437,6 +437,23 @@ __device__ __forceinline__ void record_finished(const StepArgs& a, uint32_t i, u
     a.ring[(int64_t)((episode - a.episode0) % a.ring_slots) * a.ld + i] = ret;
 }
 
+// In-kernel phase stamps (cdna_hip_programming.md section 7): only in the diagnostic build of
+// tools/microbench/step_stamps.hip (-DMT_STAMPS); in the library the macro is empty and no stamp executes.
+#ifdef MT_STAMPS
+#define MT_STAMP(a, i, slot)                                                                 \
+  do {                                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                       \
+    unsigned long long t__;                                                                  \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");              \
+    __builtin_amdgcn_sched_barrier(0);                                                       \
+    if ((a).stamps && (threadIdx.x & 63) == 0) (a).stamps[(size_t)((i) >> 6) * 8 + (slot)] = t__; \
+  } while (0)
+#else
+#define MT_STAMP(a, i, slot) \
+  do {                       \
+  } while (0)
+#endif
+
 // Staged actions come from outside (a policy, a host array): anything that is not a finite angle of at most
 // 2^15 degrees in magnitude -- NaN, +-inf, garbage -- would poison `goals` for good.  Tested on the bit pattern,
 // so the check survives -ffinite-math-only.
@@ -447,8 +464,15 @@ __device__ __forceinline__ bool unusable_angle(float v) { return (__float_as_uin
 template <class Tbl, int TRIG>
 constexpr int step_min_waves() { return (TRIG == 0 && Tbl::D >= 6 && Tbl::D <= 7) ? 8 : 1; }
 
-template <class Tbl, bool SAMPLE, int TRIG, bool LDS>
-__global__ __launch_bounds__(kBlock, (step_min_waves<Tbl, TRIG>())) void step_kernel(const StepArgs a) {
+//   PF     : number of targets whose coordinates are requested at the very top, ahead of the kinematics (0 or
+//            kPrefetch).  In-kernel stamps (tools/microbench/step_stamps.hip) show that with few waves per SIMD the
+//            target loop is a chain of exposed load latencies -- 55 % of a wave's lifetime at 65 536 arms -- which the
+//            ~3700 cycles of kinematics hide completely if the loads are already in flight.  Costs 3 * PF registers,
+//            so the host uses it where occupancy is not the limit (small batches); same arithmetic, same bits.
+constexpr int kPrefetch = 8;
+
+template <class Tbl, bool SAMPLE, int TRIG, bool LDS, int PF = 0>
+__global__ __launch_bounds__(kBlock, (PF ? 1 : step_min_waves<Tbl, TRIG>())) void step_kernel(const StepArgs a) {
   constexpr int D = Tbl::D;
   __shared__ DhConst sh;
   if (LDS) {
@@ -466,14 +490,25 @@ __global__ __launch_bounds__(kBlock, (step_min_waves<Tbl, TRIG>())) void step_ke
   // Long arms (D >= 6) are register-bound: their kernel keeps nothing alive across the sub-step loops that it can
   // fetch or store on the other side of them (alive mask and return loaded after, new goals stored before).
   constexpr bool kLean = D >= 6;
+  MT_STAMP(a, i, 0);
   float g[D], act[D];
 #pragma unroll
   for (int j = 0; j < D; ++j) g[j] = ldr(a.goals + j * ld, i * 4u);
+  float tx[PF ? PF : 1][3];
+  if (PF) {
+#pragma unroll
+    for (int k = 0; k < PF; ++k)
+      if (k < a.K) {
+        const float* row = a.points + (int64_t)(3 * k) * ld;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) tx[k][q] = ldr(row + q * ld, i * 4u);
+      }
+  }
   // The alive mask and the return are requested now, ahead of the arithmetic that does not need them.
   // (Requesting the target rows here as well was measured: no gain, -2 waves/SIMD -- profiles/r01_variants.md.)
   uint32_t am = 0;
   float total_in = 0.f;
-  if (!kLean) {
+  if (!kLean || PF) {
     am = ldr(a.alive, i * 4u);
     total_in = ldr(a.total_reward, i * 4u);
   }
@@ -493,6 +528,7 @@ __global__ __launch_bounds__(kBlock, (step_min_waves<Tbl, TRIG>())) void step_ke
       atomicAdd(a.bad_actions, 1u);
     }
   }
+  MT_STAMP(a, i, 1);  // action known (Philox done / staged action loaded)
   if (kLean) {  // goals = action (manytor.py:184): the old pose is in registers already
 #pragma unroll
     for (int j = 0; j < D; ++j) str(a.goals + j * ld, i * 4u, act[j]);
@@ -501,14 +537,20 @@ __global__ __launch_bounds__(kBlock, (step_min_waves<Tbl, TRIG>())) void step_ke
   float el[3], e[3];
   const float zmin = route_kinematics<Tbl, TRIG>(t, a.S, a.inv_sm1, g, act, el, e);
   const bool ground = zmin < 0.f;  // manytor.py:191
-  if (kLean) {
+  if (kLean && !PF) {
     am = ldr(a.alive, i * 4u);
     total_in = ldr(a.total_reward, i * 4u);
   }
+  MT_STAMP(a, i, 2);  // kinematics done (this waits for the pose loads)
 
   // obs2 (before pickup, manytor.py:204) and pickup (manytor.py:206) per target
   uint32_t nam = am;
-  for (int k = 0; k < a.K; ++k) {
+  if (PF) {
+#pragma unroll
+    for (int k = 0; k < PF; ++k)
+      if (k < a.K) step_target<false>(a, ld, i, k, am, nam, el, e, tx[k][0], tx[k][1], tx[k][2]);
+  }
+  for (int k = PF; k < a.K; ++k) {
     if (TRIG == 5) {  // DIAGNOSTIC: arithmetic only, no HBM traffic for targets / observations
       float dist, r, th;
       const float x = (float)(i & 63) + (float)k, y = 3.0f + (float)k, z = 5.0f + g[0];
@@ -521,6 +563,7 @@ __global__ __launch_bounds__(kBlock, (step_min_waves<Tbl, TRIG>())) void step_ke
     step_target<TRIG == 4>(a, ld, i, k, am, nam, el, e, ldr(row, i * 4u), ldr(row + ld, i * 4u), ldr(row + 2 * ld, i * 4u));
   }
 
+  MT_STAMP(a, i, 3);  // target loop done
   const int32_t rew = ground ? -1 : ((nam != am) ? 1 : 0);  // manytor.py:205-212
   bool done = (nam == 0u);                                    // manytor.py:170-171
   if (a.flags & MT_FLAG_TERMINATE_ON_GROUND) done |= ground;
@@ -537,6 +580,11 @@ __global__ __launch_bounds__(kBlock, (step_min_waves<Tbl, TRIG>())) void step_ke
   str_stream(a.done, i, (uint8_t)(done ? 1 : 0));
   const unsigned long long bits = __ballot(done);
   if ((threadIdx.x & 63) == 0) a.done_bits[i >> 6] = bits;
+  MT_STAMP(a, i, 4);  // all stores issued
+#ifdef MT_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  MT_STAMP(a, i, 5);  // all stores acknowledged
+#endif
 }
 
 // Sub-step trajectory of the whole batch (manytor.py:190 appends joints_coordinates[3] of every

@@ -42,6 +42,9 @@ struct StepArgs {
   uint32_t flags;
   uint32_t seed_lo, seed_hi, major;  // RNG key + step / episode index
   DhConst dh;
+#ifdef MT_STAMPS
+  unsigned long long* stamps;  // diagnostic build only (tools/microbench/step_stamps.hip): [waves][8] shader-clock stamps
+#endif
 };
 
 }  // namespace mt

@@ -12,7 +12,13 @@ sys.path.insert(0, ROOT)
 import manytor_amd as m  # noqa: E402
 
 
-def us_per_step(n, steps=600, fused=False, **kw):
+def us_per_step(n, steps=600, fused=False, prefetch=None, dof7=False, **kw):
+    if prefetch is None:
+        os.environ.pop("MT_PREFETCH", None)
+    else:
+        os.environ["MT_PREFETCH"] = str(int(prefetch))
+    if dof7:
+        kw.update(dh_table=m.DH7_TABLE, radius=92.6)
     e = m.StepEngine(n, 7, **kw)
     e.reset_random(1, 0)
     t0 = time.perf_counter()
@@ -38,8 +44,12 @@ def us_per_step(n, steps=600, fused=False, **kw):
 
 def main():
     out = {}
-    for n in (16384, 65536, 131072, 262144, 524288):
+    for n in (16384, 65536, 131072, 262144, 524288, 1048576):
         out[n] = {
+            "streaming_variant(MT_PREFETCH=0)": us_per_step(n, prefetch=0),
+            "latency_variant(MT_PREFETCH=1)": us_per_step(n, prefetch=1),
+            "7dof_streaming": us_per_step(n, prefetch=0, dof7=True),
+            "7dof_latency": us_per_step(n, prefetch=1, dof7=True),
             "full": us_per_step(n),
             "no_interior_substeps(ablate1)": us_per_step(n, ablate=1),
             "memory_only(ablate2)": us_per_step(n, ablate=2),
