@@ -14,6 +14,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 import manytor_amd as m  # noqa: E402
 from oracle import manytor_oracle as mo  # noqa: E402
 from tests.test_gpu_parity import Lockstep  # noqa: E402
