@@ -469,6 +469,8 @@ constexpr int step_min_waves() { return (TRIG == 0 && Tbl::D >= 6 && Tbl::D <= 7
 //            target loop is a chain of exposed load latencies -- 55 % of a wave's lifetime at 65 536 arms -- which the
 //            ~3700 cycles of kinematics hide completely if the loads are already in flight.  Costs 3 * PF registers,
 //            so the host uses it where occupancy is not the limit (small batches); same arithmetic, same bits.
+//            (Staging the same rows through LDS-DMA -- global_load_lds_dword into a [3K][256] tile, no VGPRs -- was
+//            measured and is slower at every batch size: profiles/r02_variants.md section 5.)
 constexpr int kPrefetch = 8;
 
 template <class Tbl, bool SAMPLE, int TRIG, bool LDS, int PF = 0>

@@ -44,18 +44,16 @@ def us_per_step(n, steps=600, fused=False, prefetch=None, dof7=False, **kw):
 
 def main():
     out = {}
-    for n in (16384, 65536, 131072, 262144, 524288, 1048576):
+    for n in (16384, 65536, 131072, 262144, 524288, 1048576, 4194304):
         out[n] = {
             "streaming_variant(MT_PREFETCH=0)": us_per_step(n, prefetch=0),
-            "latency_variant(MT_PREFETCH=1)": us_per_step(n, prefetch=1),
+            "latency_variant_registers(MT_PREFETCH=1)": us_per_step(n, prefetch=1),
             "7dof_streaming": us_per_step(n, prefetch=0, dof7=True),
-            "7dof_latency": us_per_step(n, prefetch=1, dof7=True),
+            "7dof_latency_registers": us_per_step(n, prefetch=1, dof7=True),
             "full": us_per_step(n),
-            "no_interior_substeps(ablate1)": us_per_step(n, ablate=1),
-            "memory_only(ablate2)": us_per_step(n, ablate=2),
-            "arithmetic_only(ablate3)": us_per_step(n, ablate=3),
             "fused_rollout_per_step": us_per_step(n, fused=True),
-            "runtime_table": us_per_step(n, specialize=False),
+            "runtime_table_streaming": us_per_step(n, specialize=False, prefetch=0),
+            "runtime_table_latency": us_per_step(n, specialize=False, prefetch=1),
         }
     print(json.dumps(out, indent=1))
 
