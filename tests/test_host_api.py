@@ -47,17 +47,59 @@ def test_ctypes_struct_matches_c_layout(lib, tmp_path):
     src = tmp_path / "sz.c"
     src.write_text(
         '#include <stdio.h>\n#include <stddef.h>\n#include "manytor_hip.h"\n'
-        'int main(void){printf("%zu %zu %zu %zu %zu\\n", sizeof(mt_config), offsetof(mt_config,n_envs),'
-        ' offsetof(mt_config,dof), offsetof(mt_config,pickup_tol), offsetof(mt_config,dh_table));return 0;}\n')
+        'int main(void){printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(mt_config), offsetof(mt_config,n_envs),'
+        ' offsetof(mt_config,dof), offsetof(mt_config,pickup_tol), offsetof(mt_config,dh_table),'
+        ' offsetof(mt_config,return_ring));return 0;}\n')
     exe = tmp_path / "sz"
     subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
     c = [int(v) for v in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
     S = _lib.MtConfig
-    assert c == [ctypes.sizeof(S), S.n_envs.offset, S.dof.offset, S.pickup_tol.offset, S.dh_table.offset]
+    assert c == [ctypes.sizeof(S), S.n_envs.offset, S.dof.offset, S.pickup_tol.offset, S.dh_table.offset,
+                 S.return_ring.offset]
     # the enums mirrored in _lib.py
     text = open(HEADER).read()
-    for name, val in (("MT_F_JOINTS", _lib.F_JOINTS), ("MT_F_TOTAL_REWARD", _lib.F_TOTAL_REWARD), ("MT_F_DONE_BITS", _lib.F_DONE_BITS)):
+    for name, val in (("MT_F_JOINTS", _lib.F_JOINTS), ("MT_F_TOTAL_REWARD", _lib.F_TOTAL_REWARD), ("MT_F_DONE_BITS", _lib.F_DONE_BITS),
+                      ("MT_F_RETURN_RING", _lib.F_RETURN_RING), ("MT_F_TRACE", _lib.F_TRACE)):
         assert int(re.search(rf"{name} = (\d+)", text).group(1)) == val
+
+
+def test_plain_c_program_links_and_calls_the_abi(lib, tmp_path):
+    """The boundary is a C ABI: a C99 translation unit (no C++, no Python) includes the header, links the shared
+    library and gets sane answers from the calls that need no GPU."""
+    from manytor_amd import _lib
+    src = tmp_path / "abi.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include <string.h>
+#include "manytor_hip.h"
+int main(void) {
+  mt_config cfg;
+  memset(&cfg, 0, sizeof cfg);
+  mt_handle h = 0;
+  int64_t total = -1;
+  uint64_t bad = 0;
+  char msg[256];
+  int rc_create, rc[4];
+  cfg.struct_size = 4; /* wrong on purpose */
+  rc_create = mt_create(&h, &cfg);
+  strncpy(msg, mt_last_error(0), sizeof msg - 1); /* the message belongs to the library until the next failing call */
+  msg[sizeof msg - 1] = 0;
+  rc[0] = mt_gather_returns(0, MT_F_TOTAL_REWARD, 0, 0, 0);
+  rc[1] = mt_comm_total_envs(0, &total);
+  rc[2] = mt_bad_action_count(0, &bad);
+  rc[3] = mt_env_step(0, 0, 0, 0, 0, 0);
+  printf("%d|%s|%d|%s|%d|%d|%d|%d\n", mt_version(), mt_status_string(MT_ERR_STATE), rc_create, msg, rc[0], rc[1], rc[2], rc[3]);
+  return h != 0;
+}
+''')
+    exe = tmp_path / "abi"
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+                    "-L", libdir, "-l:libmanytor_hip.so", f"-Wl,-rpath,{libdir}"], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.strip().split("|")
+    assert out[0] == str(lib.mt_version()) and out[1] == "invalid call order"
+    assert int(out[2]) == _lib.MT_ERR_INVALID_ARG and "struct_size" in out[3]
+    assert [int(v) for v in out[4:]] == [_lib.MT_ERR_INVALID_ARG] * 4
 
 
 def test_no_gpu_means_loud_failure_not_fallback(lib):
