@@ -161,14 +161,18 @@ def load_traffic(workload_key):
 class EpisodeLoop:
     """The benchmark's control flow, the shape of test_multi.py:17-34: `episode_len` random-action steps, then gather
     the returns of all ranks and reset every env.  `engine` needs rollout / rollout_fused / reset_random /
-    gather_returns / lap_begin / lap_end (manytor_amd.StepEngine; a stand-in in the CPU rehearsal test)."""
+    gather_begin / gather_wait / gather_returns / lap_begin / lap_end (manytor_amd.StepEngine; a stand-in in the CPU
+    rehearsal test).  With `overlap` (default) the gather is begun on the engine's side stream from a snapshot of the
+    returns and the next episode's reset and steps run beside it; its result is the previous episode's, as a learner
+    would consume it, in one of two alternating buffers."""
 
-    def __init__(self, engine, seed, episode_len, fused=False):
-        self.eng, self.seed, self.L, self.fused = engine, seed, int(episode_len), fused
+    def __init__(self, engine, seed, episode_len, fused=False, overlap=True):
+        self.eng, self.seed, self.L, self.fused, self.overlap = engine, seed, int(episode_len), fused, overlap
         self.step = 0
         self.episode = 0
         self.gathers = 0
         self.gathered = None
+        self._bufs = [None, None]
         self.eng.reset_random(seed, 0)
 
     def run(self, count, time_kernels=False):
@@ -188,15 +192,21 @@ class EpisodeLoop:
             self.step += seg
             done += seg
             if self.step % self.L == 0:
-                if time_kernels:
-                    self.eng.lap_begin("gather")
-                self.gathered = self.eng.gather_returns(self.gathered)     # RCCL all-gather (device copy at N = 1)
-                if time_kernels:
-                    self.eng.lap_end("gather")
+                if self.overlap:
+                    self.eng.gather_wait()                   # stream order only: the previous exchange finished long ago
+                    b = self.gathers % 2
+                    self._bufs[b] = self.gathered = self.eng.gather_begin(self._bufs[b])
+                    self.gathers += 1
+                else:
+                    if time_kernels:
+                        self.eng.lap_begin("gather")
+                    self.gathered = self.eng.gather_returns(self.gathered)     # RCCL all-gather (device copy at N = 1)
+                    if time_kernels:
+                        self.eng.lap_end("gather")
+                    self.gathers += 1
                 gathers += 1
                 self.episode += 1
                 self.eng.reset_random(self.seed, self.episode)
-        self.gathers += gathers
         return launches, gathers
 
 
@@ -239,7 +249,7 @@ def time_step_launches(m, n, table, radius, k, dev, seed, fused=False, steps=600
     """us per step of a secondary configuration: the same episode loop as the headline (reset every `episode_len`
     steps, so the alive masks stay those of real episodes), pre-warmed, HIP events around the step launches only."""
     e = TimedEngine(m.StepEngine(n, k, dh_table=table, radius=radius, device=dev))
-    loop = EpisodeLoop(e, seed, episode_len, fused=fused)
+    loop = EpisodeLoop(e, seed, episode_len, fused=fused, overlap=False)
     t0 = time.perf_counter()
     while time.perf_counter() - t0 < 0.15:
         loop.run(4 * episode_len)
@@ -265,6 +275,8 @@ def main():
     ap.add_argument("--episode-len", type=int, default=50)       # test_multi.py:8
     ap.add_argument("--repeats", type=int, default=0, help="timed regions (0 = enough for >= 50 ms of GPU work, 5..100)")
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x5EED)
+    ap.add_argument("--sync-gather", action="store_true",
+                    help="run the return gather in line on the engine's stream instead of overlapped on its side stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
@@ -327,7 +339,7 @@ def main():
         D.attach_gloo_gather(raw, n_total, rank, world)         # rehearsal stand-in for the RCCL gather
     eng = TimedEngine(raw)
     L = max(1, min(args.episode_len, args.steps))               # >= 1 gather inside every timed region
-    loop = EpisodeLoop(eng, args.seed, L, fused=args.fused)
+    loop = EpisodeLoop(eng, args.seed, L, fused=args.fused, overlap=not args.sync_gather)
 
     def fence():
         if world > 1:
@@ -362,7 +374,8 @@ def main():
         regions.append(time.perf_counter() - t0)
         ms = eng.collect()
         kernel_ms += ms["step"]
-        gather_ms += ms["gather"]
+        # overlapped: device time of the region's last exchange on the side stream; in line: HIP-event laps around it
+        gather_ms += (raw.gather_wait(host=True) * gt if gt else 0.0) if loop.overlap else ms["gather"]
         launches += ln
         gathers += gt
     regions = np.array(regions)
@@ -407,6 +420,8 @@ def main():
                        "targets": args.targets, "substeps": 25, "episode_len": L, "collective": collective,
                        "kernel_variant": variant, "prewarm_launches": prewarm, "repeats": repeats,
                        "gathers_in_timed_region": gathers // repeats,
+                       "gather_mode": "in line on the engine's stream" if args.sync_gather else
+                                      "overlapped: snapshot + exchange on the engine's side stream (mt_gather_returns_begin)",
                        "timing": "median over `repeats` regions of exactly `steps` steps, each bracketed by barrier + "
                                  "torch.cuda.synchronize(), max over ranks"},
             "ms_per_step_min": float(regions.min()) / args.steps * 1e3,

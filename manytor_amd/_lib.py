@@ -105,6 +105,8 @@ PROTOTYPES = {
     "mt_comm_init": (C.c_int, [_HANDLE, C.c_void_p, C.c_int, C.c_int]),
     "mt_comm_destroy": (C.c_int, [_HANDLE]),
     "mt_gather_returns": (C.c_int, [_HANDLE, C.c_int, C.c_int, C.c_void_p, C.c_int64]),
+    "mt_gather_returns_begin": (C.c_int, [_HANDLE, C.c_int, C.c_int, C.c_void_p, C.c_int64]),
+    "mt_gather_returns_wait": (C.c_int, [_HANDLE, C.c_int, C.POINTER(C.c_float)]),
     "mt_comm_total_envs": (C.c_int, [_HANDLE, C.POINTER(C.c_int64)]),
     "mt_timer_start": (C.c_int, [_HANDLE]),
     "mt_timer_stop": (C.c_int, [_HANDLE, C.POINTER(C.c_float)]),

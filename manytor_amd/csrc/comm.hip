@@ -101,6 +101,22 @@ struct mt_comm {
       return fail(h, MT_ERR_HIP, std::string(#call) + ": " + ((r)->GetErrorString ? (r)->GetErrorString(e__) : "?")); \
   } while (0)
 
+void mt_gather_release(mt_handle h) {
+  if (!h) return;
+  if (h->side_stream) {
+    (void)hipStreamSynchronize(h->side_stream);
+    (void)hipStreamDestroy(h->side_stream);
+  }
+  if (h->ev_snap) (void)hipEventDestroy(h->ev_snap);
+  if (h->ev_g0) (void)hipEventDestroy(h->ev_g0);
+  if (h->ev_g1) (void)hipEventDestroy(h->ev_g1);
+  if (h->snap) (void)hipFree(h->snap);
+  h->side_stream = nullptr;
+  h->ev_snap = h->ev_g0 = h->ev_g1 = nullptr;
+  h->snap = nullptr;
+  h->gather_pending = false;
+}
+
 void mt_comm_release(mt_handle h) {
   if (!h || !h->comm) return;
   mt_comm* c = h->comm;
@@ -191,6 +207,10 @@ int mt_comm_destroy(mt_handle h) {
   MT_REQUIRE(nullptr, h != nullptr, "handle is NULL");
   MT_ON_DEVICE(h, h->cfg.device);
   MT_HIP(h, hipStreamSynchronize(h->stream));
+  if (h->gather_pending) {
+    MT_HIP(h, hipStreamSynchronize(h->side_stream));
+    h->gather_pending = false;
+  }
   mt_comm_release(h);
   return MT_OK;
 }
@@ -202,47 +222,121 @@ int mt_comm_total_envs(mt_handle h, int64_t* total) {
   return MT_OK;
 }
 
-int mt_gather_returns(mt_handle h, int field, int row, float* dst, int64_t dst_elems) {
-  MT_REQUIRE(nullptr, h != nullptr, "handle is NULL");
-  MT_REQUIRE(h, dst != nullptr, "dst is NULL");
+// Which device row does (field, row) name?  NULL + error on a bad request.
+static const float* gather_source(mt_handle h, int field, int row, int* rc) {
   const float* src = nullptr;
   int rows = 1;
+  *rc = MT_OK;
   switch (field) {
     case MT_F_TOTAL_REWARD: src = h->args.total_reward; break;
     case MT_F_LAST_RETURN: src = h->args.last_return; break;
     case MT_F_RETURN_RING:
       src = h->args.ring;
       rows = (int)h->args.ring_slots;
-      if (!src) return fail(h, MT_ERR_STATE, "MT_F_RETURN_RING: the handle was created with return_ring = 0");
+      if (!src) {
+        *rc = fail(h, MT_ERR_STATE, "MT_F_RETURN_RING: the handle was created with return_ring = 0");
+        return nullptr;
+      }
       break;
-    default: return fail(h, MT_ERR_INVALID_ARG, "mt_gather_returns: field must be TOTAL_REWARD, LAST_RETURN or RETURN_RING");
+    default:
+      *rc = fail(h, MT_ERR_INVALID_ARG, "mt_gather_returns: field must be TOTAL_REWARD, LAST_RETURN or RETURN_RING");
+      return nullptr;
   }
-  MT_REQUIRE(h, row >= 0 && row < rows, "row out of range");
-  src += (int64_t)row * h->ld;
-  MT_ON_DEVICE(h, h->cfg.device);
+  if (row < 0 || row >= rows) {
+    *rc = fail(h, MT_ERR_INVALID_ARG, "row out of range");
+    return nullptr;
+  }
+  return src + (int64_t)row * h->ld;
+}
+
+// The exchange itself: `src` = this rank's n floats (an arena row or its snapshot), on `stream`.
+static int gather_on_stream(mt_handle h, const float* src, float* dst, int64_t dst_elems, hipStream_t stream) {
   mt_comm* c = h->comm;
   if (!c || c->world == 1) {
     MT_REQUIRE(h, dst_elems == h->n, "dst_elems must be the total number of envs");
-    MT_HIP(h, hipMemcpyAsync(dst, src, sizeof(float) * (size_t)h->n, hipMemcpyDeviceToDevice, h->stream));
+    MT_HIP(h, hipMemcpyAsync(dst, src, sizeof(float) * (size_t)h->n, hipMemcpyDeviceToDevice, stream));
     return MT_OK;
   }
   MT_REQUIRE(h, dst_elems == c->total, "dst_elems must be the total number of envs over all ranks");
   Rccl* r = rccl();
   if (!r) return fail(h, MT_ERR_UNSUPPORTED, "RCCL is not available: " + g_rccl.error);
-  if (c->equal) {  // straight from the arena row into the caller's buffer
-    MT_NCCL(h, r, r->AllGather(src, dst, (size_t)h->n, kNcclFloat32, c->comm, h->stream));
+  if (c->equal) {  // straight from the source row into the caller's buffer
+    MT_NCCL(h, r, r->AllGather(src, dst, (size_t)h->n, kNcclFloat32, c->comm, stream));
     return MT_OK;
   }
   // ragged shards: pad to the largest shard, gather, then close the gaps
   float* send = c->stage + (size_t)c->world * (size_t)c->cmax;
-  MT_HIP(h, hipMemsetAsync(send, 0, sizeof(float) * (size_t)c->cmax, h->stream));
-  MT_HIP(h, hipMemcpyAsync(send, src, sizeof(float) * (size_t)h->n, hipMemcpyDeviceToDevice, h->stream));
-  MT_NCCL(h, r, r->AllGather(send, c->stage, (size_t)c->cmax, kNcclFloat32, c->comm, h->stream));
+  MT_HIP(h, hipMemsetAsync(send, 0, sizeof(float) * (size_t)c->cmax, stream));
+  MT_HIP(h, hipMemcpyAsync(send, src, sizeof(float) * (size_t)h->n, hipMemcpyDeviceToDevice, stream));
+  MT_NCCL(h, r, r->AllGather(send, c->stage, (size_t)c->cmax, kNcclFloat32, c->comm, stream));
   int64_t off = 0;
   for (int k = 0; k < c->world; ++k) {
     MT_HIP(h, hipMemcpyAsync(dst + off, c->stage + (size_t)k * (size_t)c->cmax, sizeof(float) * (size_t)c->counts[(size_t)k],
-                             hipMemcpyDeviceToDevice, h->stream));
+                             hipMemcpyDeviceToDevice, stream));
     off += c->counts[(size_t)k];
+  }
+  return MT_OK;
+}
+
+// A gather begun with mt_gather_returns_begin and not yet waited for: order `stream` behind it.
+static int order_behind_pending_gather(mt_handle h, hipStream_t stream) {
+  if (h->gather_pending) MT_HIP(h, hipStreamWaitEvent(stream, h->ev_g1, 0));
+  return MT_OK;
+}
+
+int mt_gather_returns(mt_handle h, int field, int row, float* dst, int64_t dst_elems) {
+  MT_REQUIRE(nullptr, h != nullptr, "handle is NULL");
+  MT_REQUIRE(h, dst != nullptr, "dst is NULL");
+  int rc;
+  const float* src = gather_source(h, field, row, &rc);
+  if (!src) return rc;
+  MT_ON_DEVICE(h, h->cfg.device);
+  rc = order_behind_pending_gather(h, h->stream);  // the two forms share the communicator and its staging buffer
+  if (rc) return rc;
+  return gather_on_stream(h, src, dst, dst_elems, h->stream);
+}
+
+int mt_gather_returns_begin(mt_handle h, int field, int row, float* dst, int64_t dst_elems) {
+  MT_REQUIRE(nullptr, h != nullptr, "handle is NULL");
+  MT_REQUIRE(h, dst != nullptr, "dst is NULL");
+  int rc;
+  const float* src = gather_source(h, field, row, &rc);
+  if (!src) return rc;
+  MT_ON_DEVICE(h, h->cfg.device);
+  if (!h->side_stream) {  // first use: the side stream, its events, and the snapshot row
+    MT_HIP(h, hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
+    MT_HIP(h, hipEventCreateWithFlags(&h->ev_snap, hipEventDisableTiming));
+    MT_HIP(h, hipEventCreate(&h->ev_g0));
+    MT_HIP(h, hipEventCreate(&h->ev_g1));
+    if (hipMalloc(&h->snap, sizeof(float) * (size_t)h->n) != hipSuccess) {
+      (void)hipGetLastError();
+      return fail(h, MT_ERR_ALLOC, "hipMalloc of the return snapshot failed");
+    }
+  }
+  // the snapshot may only be overwritten once the previous exchange has read it
+  rc = order_behind_pending_gather(h, h->stream);
+  if (rc) return rc;
+  MT_HIP(h, hipMemcpyAsync(h->snap, src, sizeof(float) * (size_t)h->n, hipMemcpyDeviceToDevice, h->stream));
+  MT_HIP(h, hipEventRecord(h->ev_snap, h->stream));
+  MT_HIP(h, hipStreamWaitEvent(h->side_stream, h->ev_snap, 0));
+  MT_HIP(h, hipEventRecord(h->ev_g0, h->side_stream));
+  rc = gather_on_stream(h, h->snap, dst, dst_elems, h->side_stream);
+  if (rc) return rc;
+  MT_HIP(h, hipEventRecord(h->ev_g1, h->side_stream));
+  h->gather_pending = true;
+  return MT_OK;
+}
+
+int mt_gather_returns_wait(mt_handle h, int host_wait, float* elapsed_ms) {
+  MT_REQUIRE(nullptr, h != nullptr, "handle is NULL");
+  if (elapsed_ms) *elapsed_ms = 0.f;
+  if (!h->gather_pending) return MT_OK;
+  MT_ON_DEVICE(h, h->cfg.device);
+  MT_HIP(h, hipStreamWaitEvent(h->stream, h->ev_g1, 0));
+  if (host_wait) {
+    MT_HIP(h, hipEventSynchronize(h->ev_g1));
+    if (elapsed_ms) MT_HIP(h, hipEventElapsedTime(elapsed_ms, h->ev_g0, h->ev_g1));
+    h->gather_pending = false;
   }
   return MT_OK;
 }

@@ -405,6 +405,7 @@ int mt_destroy(mt_handle h) {
   if (!h) return MT_OK;
   DeviceGuard guard(h->cfg.device);
   (void)hipStreamSynchronize(h->stream);
+  mt_gather_release(h);  // drains the side stream before the communicator goes
   mt_comm_release(h);
   if (h->staging) (void)hipFree(h->staging);
   if (h->pinned) (void)hipHostFree(h->pinned);
@@ -436,6 +437,10 @@ int mt_use_own_stream(mt_handle h) {
 int mt_sync(mt_handle h) {
   MT_REQUIRE(nullptr, h != nullptr, "handle is NULL");
   MT_HIP(h, hipStreamSynchronize(h->stream));
+  if (h->gather_pending) {  // a gather begun on the side stream is part of "everything queued on this handle"
+    MT_HIP(h, hipStreamSynchronize(h->side_stream));
+    h->gather_pending = false;
+  }
   return MT_OK;
 }
 

@@ -35,6 +35,11 @@ struct mt_engine {
   bool prefetch = false;  // step_kernel<..., PF = kPrefetch>: target loads requested ahead of the kinematics
   int static_kind = 0;   // 0 runtime table, 1 Ref4Table, 2 Dh7Table
   mt_comm* comm = nullptr;
+  // mt_gather_returns_begin / _wait: the exchange runs on a side stream from a snapshot of the row
+  hipStream_t side_stream = nullptr;
+  hipEvent_t ev_snap = nullptr, ev_g0 = nullptr, ev_g1 = nullptr;
+  float* snap = nullptr;
+  bool gather_pending = false;
   std::string err;
 };
 
@@ -86,3 +91,4 @@ inline dim3 grid_for(int64_t n) { return dim3((unsigned)((n + kBlock - 1) / kBlo
 
 // comm.hip
 void mt_comm_release(mt_handle h);
+void mt_gather_release(mt_handle h);

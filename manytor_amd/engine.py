@@ -445,17 +445,37 @@ class StepEngine:
         self._call(self._lib.mt_comm_total_envs, C.byref(t))
         return int(t.value)
 
-    def gather_returns(self, out=None, field=None, row=0):
-        """All-gather one return row of every rank into `out`: a float32 device tensor of total_envs() elements (made
-        if None), global env order.  RCCL straight from the arena on the engine's stream; a device copy on one GPU.
-        Asynchronous: the result is ordered on the engine's stream (sync() or use_torch_stream() before reading)."""
+    def _gather_out(self, out):
         import torch
-        field = L.F_TOTAL_REWARD if field is None else field
         n_total = self.total_envs()
         if out is None:
             out = torch.empty(n_total, dtype=torch.float32, device=f"cuda:{self.device}")
         if out.dtype != torch.float32 or not out.is_cuda or not out.is_contiguous() or out.numel() != n_total:
             raise ValueError(f"out must be a contiguous float32 device tensor of {n_total} elements")
+        return out, n_total
+
+    def gather_begin(self, out=None, field=None, row=0):
+        """Start the all-gather of one return row on the engine's side stream (from a snapshot taken on its main stream)
+        and return at once: steps and resets queued next overlap with the exchange.  `out` is complete after
+        gather_wait(host=True) or sync()."""
+        field = L.F_TOTAL_REWARD if field is None else field
+        out, n_total = self._gather_out(out)
+        self._call(self._lib.mt_gather_returns_begin, int(field), int(row), C.c_void_p(out.data_ptr()), C.c_int64(n_total))
+        return out
+
+    def gather_wait(self, host=False):
+        """Order the engine's stream behind the last begun gather; host=True also blocks until its result is complete
+        and returns the device milliseconds the exchange took."""
+        ms = C.c_float(0)
+        self._call(self._lib.mt_gather_returns_wait, 1 if host else 0, C.byref(ms))
+        return ms.value if host else None
+
+    def gather_returns(self, out=None, field=None, row=0):
+        """All-gather one return row of every rank into `out`: a float32 device tensor of total_envs() elements (made
+        if None), global env order.  RCCL straight from the arena on the engine's stream; a device copy on one GPU.
+        Asynchronous: the result is ordered on the engine's stream (sync() or use_torch_stream() before reading)."""
+        field = L.F_TOTAL_REWARD if field is None else field
+        out, n_total = self._gather_out(out)
         self._call(self._lib.mt_gather_returns, int(field), int(row), C.c_void_p(out.data_ptr()), C.c_int64(n_total))
         return out
 

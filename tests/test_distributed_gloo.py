@@ -109,6 +109,11 @@ class _FakeEngine:
         ids = torch.arange(self.base, self.base + self.n, dtype=torch.float32)
         return D.gloo_gather_returns(self.ret + ids / 1e6, self.n_total)
 
+    gather_begin = gather_returns
+
+    def gather_wait(self, host=False):
+        return 0.0 if host else None
+
     def lap_begin(self, what):
         self.laps.append(what)
 

@@ -226,5 +226,26 @@ def test_gather_returns_without_and_with_a_one_rank_rccl_communicator(m):
     np.testing.assert_array_equal(out.cpu().numpy(), eng.last_return())
     with pytest.raises(ValueError):
         eng.gather_returns(torch.zeros(n - 1, dtype=torch.float32, device="cuda"))
+    # overlapped form, through the communicator: snapshot on the engine's stream, exchange on its side stream; the
+    # reset and the steps queued right behind it must not leak into the result
+    for rep in range(3):
+        want = eng.total_reward()
+        out3 = eng.gather_begin(out3 if rep else None)
+        eng.reset_random(2, rep + 1)                         # zeroes the returns while the exchange may still run
+        eng.rollout(4 + rep, 2, 0)
+        ms = eng.gather_wait(host=True)
+        assert ms is not None and ms >= 0.0
+        np.testing.assert_array_equal(out3.cpu().numpy(), want)
+        assert np.abs(want).max() > 0
+    out4 = eng.gather_begin()                                # ... and sync() alone also covers a begun gather
+    want = eng.total_reward()
+    eng.reset_random(2, 9)
+    eng.sync()
+    np.testing.assert_array_equal(out4.cpu().numpy(), want)
     eng.comm_destroy()
+    # without a communicator the overlapped form is a device copy on the side stream
+    out5 = eng.gather_begin()
+    eng.rollout(3, 2, 0)
+    eng.gather_wait(host=True)
+    np.testing.assert_array_equal(out5.cpu().numpy(), np.zeros(n, dtype=np.float32))
     eng.close()
