@@ -99,6 +99,22 @@ void launch_step_t(mt_handle h, const StepArgs& args, bool sample) {
     }
     return;
   }
+  if (h->trig == 0 && h->split) {  // tiny batches: one env over 2 or 4 lanes (kernels.h, step_split_kernel)
+    const int64_t per_block = kBlock / h->split;
+    const dim3 gs((unsigned)((args.n + per_block - 1) / per_block));
+    if (h->split == 2) {
+      if (sample)
+        hipLaunchKernelGGL((step_split_kernel<Tbl, true, 2>), gs, b, 0, h->stream, args);
+      else
+        hipLaunchKernelGGL((step_split_kernel<Tbl, false, 2>), gs, b, 0, h->stream, args);
+    } else {
+      if (sample)
+        hipLaunchKernelGGL((step_split_kernel<Tbl, true, 4>), gs, b, 0, h->stream, args);
+      else
+        hipLaunchKernelGGL((step_split_kernel<Tbl, false, 4>), gs, b, 0, h->stream, args);
+    }
+    return;
+  }
   if (h->trig == 0 && h->prefetch) {  // small batches: target loads in flight before the kinematics (kernels.h, PF)
     if (sample)
       hipLaunchKernelGGL((step_kernel<Tbl, true, 0, false, kPrefetch>), g, b, 0, h->stream, args);
@@ -308,9 +324,11 @@ int mt_create(mt_handle* out, const mt_config* cfg) {
   h->cfg = *cfg;
   h->n = cfg->n_envs;
   h->ld = (int64_t)align_up((size_t)cfg->n_envs, 256);
-  // Rows that are an exact power of two apart alias onto the same HBM channels; 4 KiB of padding per row
-  // measured +2..6 % (profiles/README.md).  MT_LD_PAD (floats) overrides it for experiments.
-  int64_t pad = (cfg->n_envs > 16384) ? 1024 : 0;
+  // Rows that are an exact power of two apart alias onto the same HBM channels, so every row gets a pad.  1 KiB
+  // (256 floats): round 1 used 4 KiB, which is fine at 1 M arms but pathological at 262 144 (row stride 1 MiB + 4 KiB:
+  // 14.7 us per step against 11.7 with 1 KiB; tools/pad_sweep.py, profiles/r02_variants.md section 6); 1 KiB is within
+  // 1 % of the best pad at every size tried.  MT_LD_PAD (floats) overrides it for experiments.
+  int64_t pad = (cfg->n_envs > 16384) ? 256 : 0;
   if (const char* env = std::getenv("MT_LD_PAD")) pad = (int64_t)align_up((size_t)std::atoll(env), 64);
   h->ld += pad;
   h->D = cfg->dof;
@@ -319,11 +337,25 @@ int mt_create(mt_handle* out, const mt_config* cfg) {
   if (cfg->flags & MT_FLAG_ABLATE_LOOP) h->trig = (cfg->flags & MT_FLAG_ABLATE_OBS) ? 4 : 3;
   else if (cfg->flags & MT_FLAG_ABLATE_OBS) h->trig = 5;   /* OBS alone = arithmetic-only build */
   h->lds_table = (cfg->flags & MT_FLAG_DH_IN_LDS) != 0;
-  // Latency variant of the step kernel for batches that leave the chip under-occupied (<= 2 waves per SIMD: measured
-  // 7.08 -> 6.43 us at 65 536 arms, 7.86 -> 7.14 at 131 072, but 14.7 -> 15.2 at 262 144; profiles/r02_variants.md section 3);
-  // the streaming variant everywhere else.  MT_PREFETCH=0/1 overrides the choice for experiments.
-  h->prefetch = cfg->n_envs <= 131072;
-  if (const char* env = std::getenv("MT_PREFETCH")) h->prefetch = std::atoi(env) != 0;
+  // Which step kernel for which batch (tools/variant_sweep.py, profiles/r02_variants.md section 3; all variants give
+  // the same bits):
+  //   <= 32 768 arms   one env over 4 lanes   (4.2-5.0 us per step against 5.6-6.2)
+  //   <= 65 536        one env over 2 lanes   (5.8-5.9 against 6.2-6.4)
+  //   above            one env per lane, with the targets prefetched into registers (PF) for the reference arm at every
+  //                    size (7.1 against 7.8 us at 131 072 arms, 19.9 against 21.0 at 524 288, 39.4 against 39.5 at 1 M)
+  //                    and for other arms up to 131 072 arms (long arms lose more to the lower occupancy than they gain)
+  // MT_SPLIT = 0/2/4 and MT_PREFETCH = 0/1 override the choice for experiments and tests.
+  h->split = cfg->n_envs <= 32768 ? 4 : (cfg->n_envs <= 65536 ? 2 : 0);
+  h->prefetch = cfg->n_envs <= 131072;  // widened for the reference arm once the table is known (below)
+  if (const char* env = std::getenv("MT_SPLIT")) {
+    const int v = std::atoi(env);
+    h->split = (v == 2 || v == 4) ? v : 0;
+  }
+  h->prefetch_forced = false;
+  if (const char* env = std::getenv("MT_PREFETCH")) {
+    h->prefetch = std::atoi(env) != 0;
+    h->prefetch_forced = true;
+  }
 
   auto bail = [&](int code, const std::string& msg) {
     g_last_error = msg;
@@ -396,6 +428,7 @@ int mt_create(mt_handle* out, const mt_config* cfg) {
   a.flags = cfg->flags;
   a.dh = make_dh(cfg->dh_table, h->D);
   h->static_kind = (cfg->flags & (MT_FLAG_NO_SPECIALIZE | MT_FLAG_DH_IN_LDS)) ? 0 : match_static(a.dh, h->D);
+  if (h->static_kind == 1 && !h->prefetch_forced) h->prefetch = true;
 #undef MT_HIP_C
   *out = h;
   return MT_OK;

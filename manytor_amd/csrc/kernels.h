@@ -589,6 +589,184 @@ __global__ __launch_bounds__(kBlock, (PF ? 1 : step_min_waves<Tbl, TRIG>())) voi
 #endif
 }
 
+// ---------------------------------------------------------------------------
+// step, one env spread over L lanes of a wave (L = 2 or 4) -- for batches so small that the chip is mostly idle and a
+// launch's time is one wave's dependent chain plus the kernel boundary (profiles/r02_variants.md section 3).
+//   lane layout   : lane = q * (64 / L) + e;  e = env within the wave (64 / L envs per wave), q = its sub-lane
+//   kinematics    : sub-lanes with even q walk the forward half of the recurrence (from the previous pose), odd q the
+//                   backward half (from the action) -- the SAME loop body, the sign of sin(delta) and the start state
+//                   differ per lane, so there is no divergence; every pose keeps the arithmetic of route_kinematics
+//                   (-(s * -sd) == s * sd exactly), and min over the halves is order-free => bit-identical results
+//   targets       : sub-lane q handles targets q, q + L, q + 2L, ...; the cleared alive bits are AND-ed over the
+//                   sub-lanes, the running min of z is min-ed (ds_bpermute via __shfl_xor)
+//   replicated    : the Philox draw, the endpoint sincos and the full chain at the final pose (every sub-lane needs the
+//                   elbow and the end effector for its targets)
+//   stores        : each sub-lane its targets' observations; sub-lane 0 the env's state and step outputs
+// Only the default trigonometry (TRIG 0); D, the table kinds and both action sources as in step_kernel.
+// ---------------------------------------------------------------------------
+template <class Tbl, bool SAMPLE, int L>
+__global__ __launch_bounds__(kBlock) void step_split_kernel(const StepArgs a) {
+  static_assert(L == 2 || L == 4, "an env is spread over 2 or 4 lanes");
+  constexpr int D = Tbl::D;
+  constexpr int JN = ZJoints<Tbl>::value;
+  constexpr int EPW = 64 / L;                                  // envs per wave
+  constexpr int PFS = (kPrefetch + L - 1) / L;                 // targets per sub-lane requested up front
+  const Tbl t = TableMaker<Tbl>::make(a.dh);
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  const uint32_t q = lane / EPW;
+  const int64_t first = (int64_t)wave * EPW;                   // first env of this wave
+  if (first >= a.n) return;                                    // whole wave beyond the batch
+  const uint32_t env = (uint32_t)first + lane % EPW;
+  const bool live = env < a.n;                                 // tail lanes compute on the last env and store nothing
+  const uint32_t i = live ? env : (uint32_t)(a.n - 1);
+  const int64_t ld = a.ld;
+
+  float g[D], act[D];
+#pragma unroll
+  for (int j = 0; j < D; ++j) g[j] = (a.goals + j * ld)[i];
+  // this sub-lane's first targets, ahead of the arithmetic (target index p = q + L * m)
+  float tx[PFS][3];
+#pragma unroll
+  for (int m = 0; m < PFS; ++m) {
+    const int p = (int)q + L * m;
+    if (p < a.K) {
+      const float* row = a.points + (int64_t)(3 * p) * ld;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) tx[m][c] = (row + c * ld)[i];
+    }
+  }
+  const uint32_t am = a.alive[i];
+  const float total_in = a.total_reward[i];
+  if (SAMPLE) {
+    draw_action<D>(((uint64_t)a.seed_hi << 32) | a.seed_lo, (uint64_t)(a.env_base + i), a.major, act);
+  } else {
+    bool bad = false;
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      act[j] = (a.actions + j * ld)[i];
+      bad |= unusable_angle(act[j]);
+    }
+    if (bad) {
+#pragma unroll
+      for (int j = 0; j < D; ++j) act[j] = g[j];
+      if (live && q == 0) atomicAdd(a.bad_actions, 1u);
+    }
+  }
+
+  // ---- kinematics: the poses of route_kinematics, one half per sub-lane parity ------------------------------
+  float st[D];
+#pragma unroll
+  for (int j = 0; j < D; ++j) st[j] = (act[j] - g[j]) * a.inv_sm1;
+  float sA[D], cA[D], p3[D][3], el[3], e[3];
+#pragma unroll
+  for (int j = 0; j < D; ++j) sincos_deg(act[j] + t.off(j), sA[j], cA[j]);
+  chain_all<Tbl>(sA, cA, t, p3);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    el[c] = (D > 2) ? p3[D - 2][c] : 0.f;
+    e[c] = p3[D - 1][c];
+  }
+  float sF[D], cF[D];
+#pragma unroll
+  for (int j = 0; j < D; ++j) {
+    sF[j] = 0.f;
+    cF[j] = 1.f;
+  }
+#pragma unroll
+  for (int j = 1; j < JN; ++j) sincos_deg(g[j] + t.off(j), sF[j], cF[j]);
+  float zo, ze;
+  chain_z<Tbl>(sF, cF, t, zo, ze);
+  const bool backward = (q & 1u) != 0;
+  // start state and first z of this sub-lane's half: k = 0 (previous pose) forward, k = S - 1 (the action) backward
+  float zmin = backward ? fminf(el[2], e[2]) : fminf(zo, ze);
+  float sd[D], cd[D];
+  sincos_increment<D, JN>(st, sd, cd);
+  float sW[D], cW[D];
+  sW[0] = 0.f;
+  cW[0] = 1.f;
+#pragma unroll
+  for (int j = 1; j < D; ++j) {
+    sW[j] = backward ? sA[j] : sF[j];
+    cW[j] = backward ? cA[j] : cF[j];
+    sd[j] = backward ? -sd[j] : sd[j];                         // rotate by -delta: the sign rides in the operand
+  }
+  const int nf = (a.S - 1) / 2;                                // forward poses k = 1..nf
+  const int nb = a.S - 2 - nf;                                 // backward poses k = S-2..nf+1 (nb = nf or nf - 1)
+  const int mine = backward ? nb : nf;
+#pragma unroll 2
+  for (int it = 1; it <= nf; ++it) {
+    rotate_pose<D, JN, +1>(sW, cW, sd, cd);
+    chain_z<Tbl>(sW, cW, t, zo, ze);
+    if (it <= mine) zmin = fminf(zmin, fminf(zo, ze));
+  }
+#pragma unroll
+  for (int sh = EPW; sh < 64; sh <<= 1) zmin = fminf(zmin, __shfl_xor(zmin, sh));
+  const bool ground = zmin < 0.f;  // manytor.py:191
+
+  // ---- this sub-lane's targets ------------------------------------------------------------------------------
+  uint32_t nam = am;
+  for (int m = 0; (int)q + L * m < a.K; ++m) {
+    const int p = (int)q + L * m;
+    float* row = a.points + (int64_t)(3 * p) * ld;
+    float x, y, z;
+    bool have = false;
+#pragma unroll
+    for (int mm = 0; mm < PFS; ++mm)
+      if (m == mm) {
+        x = tx[mm][0];
+        y = tx[mm][1];
+        z = tx[mm][2];
+        have = true;
+      }
+    if (!have) {
+      x = row[i];
+      y = (row + ld)[i];
+      z = (row + 2 * ld)[i];
+    }
+    const bool al = (am >> p) & 1u;
+    float dist = 0.f, r = 0.f, th = 0.f;
+    if (al) {
+      observe_target(el, x, y, z, dist, r, th);
+      if (within_box(e, x, y, z, a.tol)) nam &= ~(1u << p);
+    } else if (live && ((x != 0.f) | (y != 0.f) | (z != 0.f))) {  // manytor.py:148
+      row[i] = 0.f;
+      (row + ld)[i] = 0.f;
+      (row + 2 * ld)[i] = 0.f;
+    }
+    if (live) {
+      float* orow = a.obs + (int64_t)(3 * p) * ld;
+      __builtin_nontemporal_store(dist, orow + i);
+      __builtin_nontemporal_store(r, orow + ld + i);
+      __builtin_nontemporal_store(th, orow + 2 * ld + i);
+    }
+  }
+#pragma unroll
+  for (int sh = EPW; sh < 64; sh <<= 1) nam &= (uint32_t)__shfl_xor((int)nam, sh);
+
+  const int32_t rew = ground ? -1 : ((nam != am) ? 1 : 0);  // manytor.py:205-212
+  bool done = (nam == 0u);                                    // manytor.py:170-171
+  if (a.flags & MT_FLAG_TERMINATE_ON_GROUND) done |= ground;
+  if (live && q == 0) {
+#pragma unroll
+    for (int j = 0; j < D; ++j) (a.goals + j * ld)[i] = act[j];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) __builtin_nontemporal_store(e[c], a.ee + c * ld + i);
+    a.alive[i] = nam;
+    __builtin_nontemporal_store(rew, a.reward + i);
+    a.total_reward[i] = total_in + (float)rew;  // manytor.py:258
+    __builtin_nontemporal_store((uint8_t)(done ? 1 : 0), a.done + i);
+  }
+  // sub-lane 0 occupies lanes 0 .. EPW-1: the low EPW bits of the ballot are this wave's slice of the done_bits word
+  const unsigned long long bits = __ballot(done && live && q == 0);
+  if (lane == 0) {
+    if (L == 2)
+      reinterpret_cast<uint32_t*>(a.done_bits)[wave] = (uint32_t)bits;
+    else
+      reinterpret_cast<uint16_t*>(a.done_bits)[wave] = (uint16_t)bits;
+  }
+}
+
 // Sub-step trajectory of the whole batch (manytor.py:190 appends joints_coordinates[3] of every
 // sub-step to `trajectory`): the end effector at each of the S poses of the route goals -> action, as SoA rows
 // [3S][ld] (row 3k + axis).  Launched BEFORE the step kernel of the same call (it needs the previous pose) with the

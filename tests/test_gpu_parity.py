@@ -432,6 +432,36 @@ def test_step_random_equals_sample_then_step(m):
     np.testing.assert_array_equal(c.total_reward(), b.total_reward())
 
 
+@pytest.mark.parametrize("case", ["ref", "ref_k32", "runtime", "dh7", "rt5", "two_substeps", "terminate"])
+def test_step_kernel_variants_are_bit_identical(m, monkeypatch, case):
+    """The host picks one of four schedules of the same arithmetic by batch size: one env per lane (streaming, or with
+    the targets prefetched into registers) or one env spread over 2 / 4 lanes (step_split_kernel).  Forced here through
+    MT_SPLIT / MT_PREFETCH on the same batch: every field equal bit for bit, staged and in-kernel actions, ragged sizes."""
+    rng = np.random.RandomState(2)
+    rt5 = np.column_stack([rng.uniform(0, 9, 5), rng.choice([-np.pi / 2, 0.3, np.pi / 2], 5), rng.uniform(2, 12, 5), np.zeros(5)])
+    kw, n, k = {"ref": (dict(), 100003, 7), "ref_k32": (dict(), 65, 32), "runtime": (dict(specialize=False), 5000, 10),
+                "dh7": (dict(dh_table=m.DH7_TABLE, radius=92.6), 70001, 7), "rt5": (dict(dh_table=rt5, radius=40.0), 1234, 3),
+                "two_substeps": (dict(substeps=2), 999, 5), "terminate": (dict(terminate_on_ground=True), 4097, 7)}[case]
+    fields = ("F_GOALS", "F_ALIVE", "F_TOTAL_REWARD", "F_POINTS", "F_OBS", "F_REWARD", "F_DONE", "F_EE", "F_DONE_BITS")
+    outs = {}
+    for name, split, pf in (("streaming", 0, 0), ("prefetch", 0, 1), ("split2", 2, 0), ("split4", 4, 0)):
+        monkeypatch.setenv("MT_SPLIT", str(split))
+        monkeypatch.setenv("MT_PREFETCH", str(pf))
+        e = m.StepEngine(n, k, pickup_tol=20.0, **kw)
+        e.reset_random(3, 0)
+        e.rollout(5, 3, 0)                                      # in-kernel actions
+        acts = np.random.RandomState(1).randint(-180, 180, size=(n, e.dof)).astype(np.float32)
+        acts[n // 2, 0] = np.nan                                # one unusable action: holds its pose in every variant
+        e.step(acts)                                            # staged actions
+        outs[name] = {f: e.get(getattr(m.lib, f)) for f in fields}
+        outs[name]["bad"] = np.array(e.bad_action_count())
+        e.close()
+    for name in ("prefetch", "split2", "split4"):
+        for f, v in outs["streaming"].items():
+            np.testing.assert_array_equal(outs[name][f], v, err_msg=f"{name} {f}")
+    assert outs["streaming"]["bad"] == 1
+
+
 def test_shard_invariance(m):
     """Same seed => same per-env results however the envs are split over handles."""
     from manytor_amd.distributed import shard_range
