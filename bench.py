@@ -257,8 +257,9 @@ def time_step_launches(m, n, table, radius, k, dev, seed, fused=False, steps=600
     e.start_region()
     launches, _ = loop.run(steps, time_kernels=True)
     us = e.collect()["step"] * 1e3 / launches
+    name = "rollout_kernel (fused)" if fused else e.step_kernel_name()
     e.close()
-    return us
+    return us, name
 
 
 def main():
@@ -434,7 +435,7 @@ def main():
                 "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, committed under "
                                   "profiles/ (traffic.json); not re-measured in this run",
                 "kernel": (f"rollout_kernel<{table_name}> ({L} steps per launch; us per step quoted)" if args.fused else
-                           f"step_kernel<{table_name}, sample=true, trig={trig}, lds={str(args.dh_in_lds).lower()}>"),
+                           raw.step_kernel_name() + " (action drawn in-kernel)"),
                 "bytes_per_env_step": bpe, "avg_kernel_us": avg_kernel_s * 1e6, "kernel_launches_timed": launches,
                 "bytes_per_env_step_actual": bpe_actual,
                 "achieved_actual": bpe_actual * n_local / avg_kernel_s / 1e9,
@@ -452,7 +453,7 @@ def main():
         secondary = world == 1 and not args.fused and not args.ablate and not args.no_secondary
         if secondary:
             # informational, not the headline: the same episodes as ONE launch each
-            us = time_step_launches(m, n_local, table, radius, args.targets, dev, args.seed, fused=True, steps=1000)
+            us, _ = time_step_launches(m, n_local, table, radius, args.targets, dev, args.seed, fused=True, steps=1000)
             out["secondary"] = {"fused_rollout": {
                 "env_steps_per_s": n_local / (us * 1e-6), "us_per_step": us, "steps_per_launch": 50,
                 "note": "mt_rollout_fused: state stays in registers/LDS between steps, bit-identical results; "
@@ -463,12 +464,12 @@ def main():
                                         ("131072 arms, 4-DoF (1 M arms over 8 GPUs, per-GPU shard)", 131072, m.REF_DH_TABLE, 51.3),
                                         ("4194304 arms, 4-DoF (1 GB working set: pure HBM regime)", 4194304, m.REF_DH_TABLE, 51.3),
                                         ("configs[4]: 1048576 arms, 7-DoF table", 1048576, m.DH7_TABLE, 92.6)):
-                us = time_step_launches(m, n2, tbl, rad, args.targets, dev, args.seed,
-                                        steps=300 if n2 > (1 << 21) else 600)
+                us, kname = time_step_launches(m, n2, tbl, rad, args.targets, dev, args.seed,
+                                               steps=300 if n2 > (1 << 21) else 600)
                 b2 = algorithmic_bytes_per_env_step(len(tbl), args.targets)
                 b2a = actual_bytes_per_env_step(len(tbl), args.targets)
                 out["secondary"]["other_configs"][label] = {
-                    "us_per_step": us, "env_steps_per_s": n2 / (us * 1e-6), "bytes_per_env_step": b2,
+                    "us_per_step": us, "kernel": kname, "env_steps_per_s": n2 / (us * 1e-6), "bytes_per_env_step": b2,
                     "frac_of_hbm_peak": b2 * n2 / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                     "bytes_per_env_step_actual": b2a,
                     "frac_actual_of_hbm_peak": b2a * n2 / (us * 1e-6) / 1e9 / HBM_PEAK_GBS}

@@ -130,6 +130,10 @@ MT_API int mt_device_count(int* count);
 /* Environment()/Multienv() constructors, manytor.py:130-139 / :77-82. */
 MT_API int mt_create(mt_handle* out, const mt_config* cfg);
 MT_API int mt_destroy(mt_handle h);
+/* Which instantiation mt_step / mt_step_random launch for this handle (the schedule is picked by batch size and table
+ * at mt_create; every schedule gives the same bits): e.g. "step_kernel<Ref4Table, trig=0, lds=false, pf=8>",
+ * "step_split_kernel<RtTable<5>, L=4>".  For benchmark records and profiles; valid until the next call on the handle. */
+MT_API const char* mt_step_kernel_name(mt_handle h);
 /* Run on a caller-owned hipStream_t (e.g. torch's current stream), so that the handle's launches are ordered with
  * the caller's own work on that stream.  NULL means what it means to HIP: the legacy default stream (which is what
  * torch's default stream is).  mt_use_own_stream goes back to the handle's private non-blocking stream, which is

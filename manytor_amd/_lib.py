@@ -79,6 +79,7 @@ PROTOTYPES = {
     "mt_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "mt_create": (C.c_int, [C.POINTER(_HANDLE), C.POINTER(MtConfig)]),
     "mt_destroy": (C.c_int, [_HANDLE]),
+    "mt_step_kernel_name": (C.c_char_p, [_HANDLE]),
     "mt_set_stream": (C.c_int, [_HANDLE, C.c_void_p]),
     "mt_use_own_stream": (C.c_int, [_HANDLE]),
     "mt_sync": (C.c_int, [_HANDLE]),

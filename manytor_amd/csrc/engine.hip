@@ -451,6 +451,18 @@ int mt_destroy(mt_handle h) {
   return MT_OK;
 }
 
+const char* mt_step_kernel_name(mt_handle h) {
+  if (!h) return "";
+  const char* tbl = h->static_kind == 1 ? "Ref4Table" : (h->static_kind == 2 ? "Dh7Table" : nullptr);
+  std::string table = tbl ? tbl : "RtTable<" + std::to_string(h->D) + ">";
+  if (h->trig == 0 && !h->lds_table && h->split)
+    h->kernel_name = "step_split_kernel<" + table + ", L=" + std::to_string(h->split) + ">";
+  else
+    h->kernel_name = "step_kernel<" + table + ", trig=" + std::to_string(h->trig) + ", lds=" + (h->lds_table ? "true" : "false") +
+                     ", pf=" + ((h->trig == 0 && !h->lds_table && h->prefetch) ? std::to_string(kPrefetch) : std::string("0")) + ">";
+  return h->kernel_name.c_str();
+}
+
 int mt_set_stream(mt_handle h, void* hip_stream) {
   MT_REQUIRE(nullptr, h != nullptr, "handle is NULL");
   MT_ON_DEVICE(h, h->cfg.device);

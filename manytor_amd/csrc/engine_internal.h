@@ -43,6 +43,7 @@ struct mt_engine {
   float* snap = nullptr;
   bool gather_pending = false;
   std::string err;
+  std::string kernel_name;  // mt_step_kernel_name
 };
 
 namespace mt {

@@ -301,12 +301,26 @@ __device__ __forceinline__ void sincos_increment(const float (&st)[D], float (&s
 //   sequential (D >= 6): forward half first, then the action's sincos, the full chain and the backward half.  The two
 //     halves never hold their (s, c) state at the same time: 4 (D - 1) fewer live registers, which is what takes the
 //     7-joint kernel from 97 VGPRs (4 waves/SIMD) to <= 64 (8 waves/SIMD).
-template <class Tbl, int TRIG>
+//
+// PoseCache (rollout_kernel only): inside a rollout the pose a step starts from is the action of the step before, whose
+// sines / cosines and frame heights were computed then.  Handing them over saves the k = 0 pose's sincos and z chain
+// (JN - 1 sincos + one chain_z per step, 6 % of the instructions for the reference arm).  Same inputs to the same
+// functions, so the bits do not change; when any lane of the wave has no valid cache (first step of a launch, right
+// after an in-kernel re-arm) the whole wave simply recomputes.
+template <int D>
+struct PoseCache {
+  float s[D], c[D];  // joints 1 .. JN-1 of the pose the next step starts from
+  float zmin;        // min z of its last two frames
+};
+
+template <class Tbl, int TRIG, bool CACHED = false>
 __device__ __forceinline__ float route_kinematics(const Tbl& t, int S, float inv_sm1, const float (&g)[Tbl::D],
-                                                  const float (&act)[Tbl::D], float (&el)[3], float (&e)[3]) {
+                                                  const float (&act)[Tbl::D], float (&el)[3], float (&e)[3],
+                                                  PoseCache<Tbl::D>* cache = nullptr, bool cache_valid = false) {
   constexpr int D = Tbl::D;
   constexpr int JN = ZJoints<Tbl>::value;
   constexpr bool kSequential = (TRIG == 0 || TRIG == 5) && D >= 6;
+  const bool use_cache = CACHED && __all(cache_valid);
   // route[k] = goals + k * (action - goals) / (S-1), route[S-1] = action (np.linspace, manytor.py:182)
   float st[D];
 #pragma unroll
@@ -325,10 +339,19 @@ __device__ __forceinline__ float route_kinematics(const Tbl& t, int S, float inv
         sF[j] = 0.f;
         cF[j] = 1.f;
       }
+      if (use_cache) {
 #pragma unroll
-      for (int j = 1; j < JN; ++j) sincos_deg(g[j] + t.off(j), sF[j], cF[j]);
-      chain_z<Tbl>(sF, cF, t, zo, ze);
-      zmin = fminf(zo, ze);
+        for (int j = 1; j < JN; ++j) {
+          sF[j] = cache->s[j];
+          cF[j] = cache->c[j];
+        }
+        zmin = cache->zmin;
+      } else {
+#pragma unroll
+        for (int j = 1; j < JN; ++j) sincos_deg(g[j] + t.off(j), sF[j], cF[j]);
+        chain_z<Tbl>(sF, cF, t, zo, ze);
+        zmin = fminf(zo, ze);
+      }
 #pragma unroll 2
       for (int it = 1; it <= nf; ++it) {
         rotate_pose<D, JN, +1>(sF, cF, sd, cd);
@@ -347,6 +370,14 @@ __device__ __forceinline__ float route_kinematics(const Tbl& t, int S, float inv
       e[q] = p[D - 1][q];
     }
     zmin = fminf(zmin, fminf(el[2], e[2]));
+    if (CACHED) {
+#pragma unroll
+      for (int j = 1; j < JN; ++j) {
+        cache->s[j] = sB[j];
+        cache->c[j] = cB[j];
+      }
+      cache->zmin = fminf(el[2], e[2]);
+    }
     sB[0] = 0.f;
     cB[0] = 1.f;
 #pragma unroll 2
@@ -377,10 +408,27 @@ __device__ __forceinline__ float route_kinematics(const Tbl& t, int S, float inv
     sF[j] = 0.f;
     cF[j] = 1.f;
   }
+  if (use_cache) {
 #pragma unroll
-  for (int j = 1; j < JN; ++j) sincos_deg(g[j] + t.off(j), sF[j], cF[j]);
-  chain_z<Tbl>(sF, cF, t, zo, ze);
-  zmin = fminf(zmin, fminf(zo, ze));
+    for (int j = 1; j < JN; ++j) {
+      sF[j] = cache->s[j];
+      cF[j] = cache->c[j];
+    }
+    zmin = fminf(zmin, cache->zmin);
+  } else {
+#pragma unroll
+    for (int j = 1; j < JN; ++j) sincos_deg(g[j] + t.off(j), sF[j], cF[j]);
+    chain_z<Tbl>(sF, cF, t, zo, ze);
+    zmin = fminf(zmin, fminf(zo, ze));
+  }
+  if (CACHED) {
+#pragma unroll
+    for (int j = 1; j < JN; ++j) {
+      cache->s[j] = sA[j];
+      cache->c[j] = cA[j];
+    }
+    cache->zmin = fminf(el[2], e[2]);
+  }
 
   if (TRIG == 3 || TRIG == 4) {
     // diagnostic builds: no interior sub-steps
@@ -955,11 +1003,14 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(const StepArgs a, const
   bool ended = false, dirty = false;
   for (int k = 0; k < 3 * a.K; ++k) col[k * kBlock] = ldr(a.points + (int64_t)k * ld, i * 4u);
   const uint32_t all_alive = (a.K >= 32) ? 0xFFFFFFFFu : ((1u << a.K) - 1u);
+  PoseCache<D> pose;        // sines / cosines and frame heights of the pose the next step starts from
+  bool pose_valid = false;  // nothing known about the pose loaded from memory
 
   for (int s = 0; s < r.T; ++s) {
     float act[D], el[3], e[3];
     draw_action<D>(seed, env_id, r.step0 + (uint32_t)s, act);
-    const float zmin = route_kinematics<Tbl, 0>(t, a.S, a.inv_sm1, g, act, el, e);
+    const float zmin = route_kinematics<Tbl, 0, true>(t, a.S, a.inv_sm1, g, act, el, e, &pose, pose_valid);
+    pose_valid = true;
     const bool ground = zmin < 0.f;
 
     uint32_t nam = am;
@@ -1005,6 +1056,7 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(const StepArgs a, const
       episode += 1u;
 #pragma unroll
       for (int j = 0; j < D; ++j) g[j] = 0.f;
+      pose_valid = false;  // the cache describes the pose the finished episode ended in, not the zero pose
       draw_targets(seed, env_id, episode, a.K, r.radius, [&](int k, float x, float y, float z) {
         float* pk = col + 3 * k * kBlock;
         pk[0] = x;

@@ -126,6 +126,12 @@ class StepEngine:
             raise RuntimeError("StepEngine is closed")
         L.check(fn(self._h, *args), self._h)
 
+    def step_kernel_name(self) -> str:
+        """The kernel instantiation step() / step_random() launch for this batch (schedule picked at construction)."""
+        if not self._h:
+            raise RuntimeError("StepEngine is closed")
+        return self._lib.mt_step_kernel_name(self._h).decode()
+
     # ---- stream / sync / timing ---------------------------------------------------------------
     def set_stream(self, hip_stream):
         """Run on a caller-owned hipStream_t (int / pointer).  0 is the legacy default stream (torch's default
