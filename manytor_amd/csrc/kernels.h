@@ -637,6 +637,89 @@ __global__ __launch_bounds__(kBlock, (PF ? 1 : step_min_waves<Tbl, TRIG>())) voi
 #endif
 }
 
+// route_kinematics for an env that is spread over L lanes (step_split_kernel, rollout_split_kernel): the same S poses,
+// each with the arithmetic of route_kinematics, but a sub-lane walks only ONE half of the recurrence -- the forward half
+// from the previous pose (backward == false) or the backward half from the action -- in a loop body that is the same
+// for both (the start state and the sign of sin(delta) ride in registers), and the running min of z is combined over
+// the env's sub-lanes at the end (lane = q * (64 / L) + e, so the partners sit 64 / L, 2 * 64 / L ... lanes apart).
+// Every sub-lane computes the endpoint sincos and the full chain at the final pose itself (it needs elbow and end
+// effector for its targets).  -(s * -sd) == s * sd exactly and min is order-free => the bits of route_kinematics.
+template <class Tbl, int L, bool CACHED>
+__device__ __forceinline__ float route_kinematics_split(const Tbl& t, int S, float inv_sm1, const float (&g)[Tbl::D],
+                                                        const float (&act)[Tbl::D], bool backward, float (&el)[3],
+                                                        float (&e)[3], PoseCache<Tbl::D>* cache = nullptr,
+                                                        bool cache_valid = false) {
+  constexpr int D = Tbl::D;
+  constexpr int JN = ZJoints<Tbl>::value;
+  constexpr int EPW = 64 / L;
+  const bool use_cache = CACHED && __all(cache_valid);
+  float st[D];
+#pragma unroll
+  for (int j = 0; j < D; ++j) st[j] = (act[j] - g[j]) * inv_sm1;
+  float sA[D], cA[D], p3[D][3];
+#pragma unroll
+  for (int j = 0; j < D; ++j) sincos_deg(act[j] + t.off(j), sA[j], cA[j]);
+  chain_all<Tbl>(sA, cA, t, p3);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    el[c] = (D > 2) ? p3[D - 2][c] : 0.f;
+    e[c] = p3[D - 1][c];
+  }
+  float sF[D], cF[D];
+#pragma unroll
+  for (int j = 0; j < D; ++j) {
+    sF[j] = 0.f;
+    cF[j] = 1.f;
+  }
+  float zo, ze, z0;
+  if (use_cache) {
+#pragma unroll
+    for (int j = 1; j < JN; ++j) {
+      sF[j] = cache->s[j];
+      cF[j] = cache->c[j];
+    }
+    z0 = cache->zmin;
+  } else {
+#pragma unroll
+    for (int j = 1; j < JN; ++j) sincos_deg(g[j] + t.off(j), sF[j], cF[j]);
+    chain_z<Tbl>(sF, cF, t, zo, ze);
+    z0 = fminf(zo, ze);
+  }
+  if (CACHED) {
+#pragma unroll
+    for (int j = 1; j < JN; ++j) {
+      cache->s[j] = sA[j];
+      cache->c[j] = cA[j];
+    }
+    cache->zmin = fminf(el[2], e[2]);
+  }
+  // start state and first z of this sub-lane's half: k = 0 (previous pose) forward, k = S - 1 (the action) backward
+  float zmin = backward ? fminf(el[2], e[2]) : z0;
+  float sd[D], cd[D];
+  sincos_increment<D, JN>(st, sd, cd);
+  float sW[D], cW[D];
+  sW[0] = 0.f;
+  cW[0] = 1.f;
+#pragma unroll
+  for (int j = 1; j < D; ++j) {
+    sW[j] = backward ? sA[j] : sF[j];
+    cW[j] = backward ? cA[j] : cF[j];
+    sd[j] = backward ? -sd[j] : sd[j];                         // rotate by -delta: the sign rides in the operand
+  }
+  const int nf = (S - 1) / 2;                                  // forward poses k = 1..nf
+  const int nb = S - 2 - nf;                                   // backward poses k = S-2..nf+1 (nb = nf or nf - 1)
+  const int mine = backward ? nb : nf;
+#pragma unroll 2
+  for (int it = 1; it <= nf; ++it) {
+    rotate_pose<D, JN, +1>(sW, cW, sd, cd);
+    chain_z<Tbl>(sW, cW, t, zo, ze);
+    if (it <= mine) zmin = fminf(zmin, fminf(zo, ze));
+  }
+#pragma unroll
+  for (int sh = EPW; sh < 64; sh <<= 1) zmin = fminf(zmin, __shfl_xor(zmin, sh));
+  return zmin;
+}
+
 // ---------------------------------------------------------------------------
 // step, one env spread over L lanes of a wave (L = 2 or 4) -- for batches so small that the chip is mostly idle and a
 // launch's time is one wave's dependent chain plus the kernel boundary (profiles/r02_variants.md section 3).
@@ -656,7 +739,6 @@ template <class Tbl, bool SAMPLE, int L>
 __global__ __launch_bounds__(kBlock) void step_split_kernel(const StepArgs a) {
   static_assert(L == 2 || L == 4, "an env is spread over 2 or 4 lanes");
   constexpr int D = Tbl::D;
-  constexpr int JN = ZJoints<Tbl>::value;
   constexpr int EPW = 64 / L;                                  // envs per wave
   constexpr int PFS = (kPrefetch + L - 1) / L;                 // targets per sub-lane requested up front
   const Tbl t = TableMaker<Tbl>::make(a.dh);
@@ -703,53 +785,8 @@ __global__ __launch_bounds__(kBlock) void step_split_kernel(const StepArgs a) {
   }
 
   // ---- kinematics: the poses of route_kinematics, one half per sub-lane parity ------------------------------
-  float st[D];
-#pragma unroll
-  for (int j = 0; j < D; ++j) st[j] = (act[j] - g[j]) * a.inv_sm1;
-  float sA[D], cA[D], p3[D][3], el[3], e[3];
-#pragma unroll
-  for (int j = 0; j < D; ++j) sincos_deg(act[j] + t.off(j), sA[j], cA[j]);
-  chain_all<Tbl>(sA, cA, t, p3);
-#pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    el[c] = (D > 2) ? p3[D - 2][c] : 0.f;
-    e[c] = p3[D - 1][c];
-  }
-  float sF[D], cF[D];
-#pragma unroll
-  for (int j = 0; j < D; ++j) {
-    sF[j] = 0.f;
-    cF[j] = 1.f;
-  }
-#pragma unroll
-  for (int j = 1; j < JN; ++j) sincos_deg(g[j] + t.off(j), sF[j], cF[j]);
-  float zo, ze;
-  chain_z<Tbl>(sF, cF, t, zo, ze);
-  const bool backward = (q & 1u) != 0;
-  // start state and first z of this sub-lane's half: k = 0 (previous pose) forward, k = S - 1 (the action) backward
-  float zmin = backward ? fminf(el[2], e[2]) : fminf(zo, ze);
-  float sd[D], cd[D];
-  sincos_increment<D, JN>(st, sd, cd);
-  float sW[D], cW[D];
-  sW[0] = 0.f;
-  cW[0] = 1.f;
-#pragma unroll
-  for (int j = 1; j < D; ++j) {
-    sW[j] = backward ? sA[j] : sF[j];
-    cW[j] = backward ? cA[j] : cF[j];
-    sd[j] = backward ? -sd[j] : sd[j];                         // rotate by -delta: the sign rides in the operand
-  }
-  const int nf = (a.S - 1) / 2;                                // forward poses k = 1..nf
-  const int nb = a.S - 2 - nf;                                 // backward poses k = S-2..nf+1 (nb = nf or nf - 1)
-  const int mine = backward ? nb : nf;
-#pragma unroll 2
-  for (int it = 1; it <= nf; ++it) {
-    rotate_pose<D, JN, +1>(sW, cW, sd, cd);
-    chain_z<Tbl>(sW, cW, t, zo, ze);
-    if (it <= mine) zmin = fminf(zmin, fminf(zo, ze));
-  }
-#pragma unroll
-  for (int sh = EPW; sh < 64; sh <<= 1) zmin = fminf(zmin, __shfl_xor(zmin, sh));
+  float el[3], e[3];
+  const float zmin = route_kinematics_split<Tbl, L, false>(t, a.S, a.inv_sm1, g, act, (q & 1u) != 0, el, e);
   const bool ground = zmin < 0.f;  // manytor.py:191
 
   // ---- this sub-lane's targets ------------------------------------------------------------------------------
@@ -1074,6 +1111,138 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(const StepArgs a, const
   if (ended) str(a.episodes, i * 4u, episode);
   if (dirty)
     for (int k = 0; k < 3 * a.K; ++k) str(a.points + (int64_t)k * ld, i * 4u, col[k * kBlock]);
+}
+
+// rollout with one env spread over L lanes (L = 2 or 4): rollout_kernel for batches so small that a step's time is one
+// wave's dependent chain.  Lane layout, kinematics halves and target partition as in step_split_kernel; joint angles,
+// alive mask, return and episode counter are replicated in the env's sub-lanes (they all see the same combined z-min and
+// alive mask, so they stay equal); the targets live in LDS, one column per ENV ([3K][kBlock / L]), written by whichever
+// sub-lane owns the target.  A wave only ever touches its own columns: wave_barrier() orders the LDS traffic, no
+// block barrier.  Bit-identical to rollout_kernel.
+template <class Tbl, int L>
+__global__ __launch_bounds__(kBlock) void rollout_split_kernel(const StepArgs a, const RolloutArgs r) {
+  static_assert(L == 2 || L == 4, "an env is spread over 2 or 4 lanes");
+  extern __shared__ float tile[];  // [3K][kBlock / L]
+  constexpr int D = Tbl::D;
+  constexpr int EPW = 64 / L;
+  constexpr int EPB = kBlock / L;  // envs per block = columns of the tile
+  const Tbl t = TableMaker<Tbl>::make(a.dh);
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  const uint32_t q = lane / EPW;
+  const int64_t first = (int64_t)wave * EPW;
+  if (first >= a.n) return;
+  const uint32_t env = (uint32_t)first + lane % EPW;
+  const bool live = env < a.n;  // tail lanes work on a copy of the last env (in their own column) and store nothing
+  const uint32_t i = live ? env : (uint32_t)(a.n - 1);
+  const int64_t ld = a.ld;
+  const uint64_t seed = ((uint64_t)a.seed_hi << 32) | a.seed_lo;
+  const uint64_t env_id = (uint64_t)(a.env_base + i);
+  float* col = tile + (threadIdx.x >> 6) * EPW + lane % EPW;
+  const bool backward = (q & 1u) != 0;
+
+  float g[D];
+#pragma unroll
+  for (int j = 0; j < D; ++j) g[j] = (a.goals + j * ld)[i];
+  uint32_t am = a.alive[i];
+  float total = a.total_reward[i];
+  uint32_t episode = r.auto_reset ? a.episodes[i] : 0u;
+  bool ended = false, dirty = false;
+  for (int p = (int)q; p < a.K; p += L) {  // this sub-lane's targets into the env's column
+    const float* row = a.points + (int64_t)(3 * p) * ld;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) col[(3 * p + c) * EPB] = (row + c * ld)[i];
+  }
+  const uint32_t all_alive = (a.K >= 32) ? 0xFFFFFFFFu : ((1u << a.K) - 1u);
+  PoseCache<D> pose;
+  bool pose_valid = false;
+
+  for (int s = 0; s < r.T; ++s) {
+    float act[D], el[3], e[3];
+    draw_action<D>(seed, env_id, r.step0 + (uint32_t)s, act);
+    const float zmin = route_kinematics_split<Tbl, L, true>(t, a.S, a.inv_sm1, g, act, backward, el, e, &pose, pose_valid);
+    pose_valid = true;
+    const bool ground = zmin < 0.f;
+
+    uint32_t nam = am;
+    for (int p = (int)q; p < a.K; p += L) {
+      float* pk = col + 3 * p * EPB;
+      const float x = pk[0], y = pk[EPB], z = pk[2 * EPB];
+      const bool al = (am >> p) & 1u;
+      float dist = 0.f, rr = 0.f, th = 0.f;
+      if (al) {
+        observe_target(el, x, y, z, dist, rr, th);
+        if (within_box(e, x, y, z, a.tol)) nam &= ~(1u << p);
+      } else if ((x != 0.f) | (y != 0.f) | (z != 0.f)) {  // manytor.py:148
+        pk[0] = 0.f;
+        pk[EPB] = 0.f;
+        pk[2 * EPB] = 0.f;
+        dirty = true;
+      }
+      if (live) {
+        float* orow = a.obs + (int64_t)(3 * p) * ld;
+        __builtin_nontemporal_store(dist, orow + i);
+        __builtin_nontemporal_store(rr, orow + ld + i);
+        __builtin_nontemporal_store(th, orow + 2 * ld + i);
+      }
+    }
+#pragma unroll
+    for (int sh = EPW; sh < 64; sh <<= 1) nam &= (uint32_t)__shfl_xor((int)nam, sh);
+    const int32_t rew = ground ? -1 : ((nam != am) ? 1 : 0);
+    bool done = (nam == 0u);
+    if (a.flags & MT_FLAG_TERMINATE_ON_GROUND) done |= ground;
+    total += (float)rew;
+    am = nam;
+#pragma unroll
+    for (int j = 0; j < D; ++j) g[j] = act[j];
+    if (live && q == 0) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) __builtin_nontemporal_store(e[c], a.ee + c * ld + i);
+      __builtin_nontemporal_store(rew, a.reward + i);
+      __builtin_nontemporal_store((uint8_t)(done ? (r.auto_reset ? 2 : 1) : 0), a.done + i);
+    }
+    const unsigned long long bits = __ballot(done && live && q == 0);
+    if (lane == 0) {
+      if (L == 2)
+        reinterpret_cast<uint32_t*>(a.done_bits)[wave] = (uint32_t)bits;
+      else
+        reinterpret_cast<uint16_t*>(a.done_bits)[wave] = (uint16_t)bits;
+    }
+
+    if (done && r.auto_reset) {  // re-arm, as in rollout_kernel; every sub-lane draws, each keeps its own targets
+      if (live && q == 0) record_finished(a, i, episode, total);
+      ended = true;
+      total = 0.f;
+      am = all_alive;
+      episode += 1u;
+#pragma unroll
+      for (int j = 0; j < D; ++j) g[j] = 0.f;
+      pose_valid = false;
+      draw_targets(seed, env_id, episode, a.K, r.radius, [&](int k, float x, float y, float z) {
+        if ((uint32_t)k % L == q) {
+          float* pk = col + 3 * k * EPB;
+          pk[0] = x;
+          pk[EPB] = y;
+          pk[2 * EPB] = z;
+        }
+      });
+      dirty = true;
+    }
+  }
+
+  if (live && q == 0) {
+#pragma unroll
+    for (int j = 0; j < D; ++j) (a.goals + j * ld)[i] = g[j];
+    a.alive[i] = am;
+    a.total_reward[i] = total;
+    if (ended) a.episodes[i] = episode;
+  }
+  if (live && dirty)
+    for (int p = (int)q; p < a.K; p += L) {
+      float* row = a.points + (int64_t)(3 * p) * ld;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) (row + c * ld)[i] = col[(3 * p + c) * EPB];
+    }
 }
 
 // ---------------------------------------------------------------------------

@@ -462,6 +462,31 @@ def test_step_kernel_variants_are_bit_identical(m, monkeypatch, case):
     assert outs["streaming"]["bad"] == 1
 
 
+@pytest.mark.parametrize("case", ["ref_k2", "ref_k32", "dh7", "runtime", "rt5_k1"])
+@pytest.mark.parametrize("auto_reset", [False, True])
+def test_rollout_kernel_variants_are_bit_identical(m, monkeypatch, case, auto_reset):
+    """mt_rollout_fused has the same lane-split schedules for tiny batches (rollout_split_kernel): forced through
+    MT_SPLIT on one batch, state and last-step outputs, ring and episode counters equal bit for bit."""
+    rng = np.random.RandomState(2)
+    rt5 = np.column_stack([rng.uniform(0, 9, 5), rng.choice([-np.pi / 2, 0.3, np.pi / 2], 5), rng.uniform(2, 12, 5), np.zeros(5)])
+    kw, n, k = {"ref_k2": (dict(), 20000, 2), "ref_k32": (dict(), 777, 32), "dh7": (dict(dh_table=m.DH7_TABLE, radius=92.6), 3001, 3),
+                "runtime": (dict(specialize=False), 1000, 5), "rt5_k1": (dict(dh_table=rt5, radius=40.0), 513, 1)}[case]
+    outs = {}
+    for split in (0, 2, 4):
+        monkeypatch.setenv("MT_SPLIT", str(split))
+        e = m.StepEngine(n, k, pickup_tol=25.0, **kw)
+        e.reset_random(9, 0)
+        e.rollout_fused(3, 9, 0, auto_reset=auto_reset)
+        e.rollout_fused(27, 9, 3, auto_reset=auto_reset)
+        outs[split] = {f: e.get(getattr(m.lib, f)) for f in STATE_FIELDS + STEP_FIELDS + ("F_RETURN_RING",)}
+        e.close()
+    for split in (2, 4):
+        for f, v in outs[0].items():
+            np.testing.assert_array_equal(outs[split][f], v, err_msg=f"split {split} {f}")
+    if auto_reset and case in ("ref_k2", "rt5_k1"):
+        assert outs[0]["F_EPISODES"].max() >= 2
+
+
 def test_shard_invariance(m):
     """Same seed => same per-env results however the envs are split over handles."""
     from manytor_amd.distributed import shard_range
