@@ -1,0 +1,41 @@
+"""bench.py's output contract (GPU): ONE JSON line with the keys the driver parses, sane values, and the roofline /
+cpu_baseline objects -- run as the driver runs it (a subprocess), on a reduced batch so it takes seconds."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+def test_bench_prints_one_contract_line():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5",
+                          "--envs-per-gpu", "262144", "--no-secondary"], capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["metric"] == "env-steps/sec (whole node), 1M parallel 4-DoF arms, random actions"
+    assert d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 5 and d["higher_is_better"] is True
+    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic"
+    assert "workload" in d["config"] and "model" not in d["config"] and d["config"]["gathers_in_timed_region"] >= 1
+    assert d["config"]["repeats"] >= 5 and d["config"]["prewarm_launches"] > 0
+    # value = envs x steps / (ms_per_step x steps)
+    assert d["value"] == pytest.approx(262144 / (d["ms_per_step"] * 1e-3), rel=1e-6)
+    r = d["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "bytes_per_env_step", "avg_kernel_us", "frac_actual"):
+        assert key in r, key
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert r["frac"] == pytest.approx(r["achieved"] / r["peak"]) and 0.05 < r["frac"] < 1.2
+    assert r["achieved"] == pytest.approx(249 * 262144 / (r["avg_kernel_us"] * 1e-6) / 1e9, rel=1e-6)
+    assert r["avg_kernel_us"] * 1e-3 <= d["ms_per_step"]                 # the kernel fits inside the wall-clock step
+    c = d["cpu_baseline"]
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in c, key
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 1e4
