@@ -287,6 +287,9 @@ def main():
     ap.add_argument("--rehearsal", action="store_true",
                     help="1-GPU box only: every rank on GPU 0, control AND gather over gloo (RCCL refuses two ranks on "
                          "one device); checks the N > 1 control flow, not a scaling number")
+    ap.add_argument("--single-device", action="store_true",
+                    help="testing only: every rank on GPU 0 (with MT_RCCL_LIB pointing at the stand-in transport of "
+                         "tests/fake_rccl this runs the whole N > 1 product path on a one-GPU box)")
     ap.add_argument("--hw-trig", action="store_true")
     ap.add_argument("--dh-in-lds", action="store_true")
     ap.add_argument("--direct-trig", action="store_true")
@@ -309,7 +312,7 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available() or m.device_count() < 1:
         raise SystemExit("bench.py needs a GPU: the step path has no CPU fallback")
-    dev = 0 if args.rehearsal else local_rank
+    dev = 0 if (args.rehearsal or args.single_device) else local_rank
     torch.cuda.set_device(dev)
     backend = "gloo" if args.rehearsal else args.backend
     if world > 1:
@@ -412,6 +415,9 @@ def main():
         if world > 1:
             collective = ("gloo all-gather (REHEARSAL on one device, not RCCL)" if args.rehearsal else
                           "RCCL all-gather of returns per episode through mt_gather_returns (C ABI), straight from the arena")
+            if os.environ.get("MT_RCCL_LIB", "").endswith("libfake_rccl.so"):
+                collective = "mt_gather_returns (C ABI) over the shared-memory STAND-IN for librccl (tests/fake_rccl): " \
+                             "a rehearsal of the N > 1 product path on one GPU, not a scaling number"
         out = {
             "metric": METRIC, "value": n_total * args.steps / elapsed, "unit": "env-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
