@@ -402,6 +402,12 @@ class StepEngine:
     def done(self):
         return self.get(L.F_DONE).astype(bool)
 
+    def ground_hit(self):
+        """(N,) bool: the arm touched the ground at one of the sub-step poses of the last step (manytor.py:191-192).  The
+        reference folds this into reward == -1 (:211-212) and does NOT end the episode on it (SURVEY Appendix A 5);
+        `terminate_on_ground=True` opts into ending it."""
+        return self.get(L.F_REWARD) == -1
+
     def done_bits(self):
         return self.get(L.F_DONE_BITS)
 

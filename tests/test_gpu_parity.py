@@ -395,6 +395,7 @@ def test_terminate_on_ground_flag(m):
     eng.reset(np.full((2, 1, 3), 1000.0, dtype=np.float32))
     eng.step([[0, 180, 0, 0], [0, 10, 0, 0]])
     np.testing.assert_array_equal(eng.reward(), [-1, 0])
+    np.testing.assert_array_equal(eng.ground_hit(), [True, False])
     np.testing.assert_array_equal(eng.done(), [True, False])
 
 
