@@ -207,11 +207,13 @@ class StepEngine:
             p = np.ascontiguousarray(np.asarray(points, dtype=np.float32).reshape(n, k, 3))
             self._call(self._lib.mt_reset, p.ctypes.data_as(C.c_void_p), L.ENV_MAJOR, 0)
         self.episode0 = 0
+        self._armed = True
         self.version += 1
 
     def reset_random(self, seed=0x5EED, episode=0):
         self._call(self._lib.mt_reset_random, C.c_uint64(seed), C.c_uint32(episode))
         self.episode0 = int(episode)
+        self._armed = True
         self.version += 1
 
     def env_reset(self, env, points=None, seed=0x5EED, episode=0):
@@ -382,6 +384,24 @@ class StepEngine:
         t = torch.as_tensor(holder, device=f"cuda:{self.device}")
         t._manytor_owner = holder
         return t
+
+    # ---- checkpoint / resume (the reference keeps its state in attributes, manytor.py:131-139) --------
+    def get_state(self) -> dict:
+        """Host copy of everything a step depends on: joint angles, targets, alive flags, returns (+ the step outputs
+        a caller may want to keep).  set_state() of this dict on an engine of the same shape resumes bit-identically."""
+        return {"goals": self.goals(), "points": self.points(), "alives": self.alives(), "total_reward": self.total_reward(),
+                "obs": self.obs(), "reward": self.reward(), "done": self.done(), "ee": self.ee(),
+                "episodes": self.episodes(), "last_return": self.last_return()}
+
+    def set_state(self, state: dict):
+        """Restore goals / points / alives / total_reward from get_state() (or any arrays of those shapes)."""
+        if not getattr(self, "_armed", False):
+            # a fresh handle has to be reset once before it can step; the values are overwritten right below
+            self.reset(np.asarray(state["points"], dtype=np.float32))
+        self.set(L.F_POINTS, state["points"])
+        self.set(L.F_GOALS, state["goals"])
+        self.set(L.F_ALIVE, np.asarray(state["alives"]).astype(np.uint8))
+        self.set(L.F_TOTAL_REWARD, state["total_reward"])
 
     # convenience getters in the reference's vocabulary
     def goals(self):

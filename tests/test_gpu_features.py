@@ -249,3 +249,24 @@ def test_gather_returns_without_and_with_a_one_rank_rccl_communicator(m):
     eng.gather_wait(host=True)
     np.testing.assert_array_equal(out5.cpu().numpy(), np.zeros(n, dtype=np.float32))
     eng.close()
+
+
+def test_checkpoint_and_resume_is_bit_identical(m):
+    """SURVEY 5 (checkpoint / resume): the reference's state is a handful of attributes (manytor.py:131-139);
+    get_state() / set_state() carry the same on and off the device, also into a fresh engine."""
+    n, k = 50000, 7
+    a = m.StepEngine(n, k)
+    a.reset_random(4, 0)
+    a.rollout(9, 4, 0)
+    snap = a.get_state()
+    a.rollout(6, 4, 9)
+    want = a.get_state()
+    b = m.StepEngine(n, k)                                   # a fresh engine, never reset
+    b.set_state(snap)
+    b.rollout(6, 4, 9)
+    got = b.get_state()
+    for key in ("goals", "points", "alives", "total_reward", "obs", "reward", "done", "ee"):
+        np.testing.assert_array_equal(got[key], want[key], err_msg=key)
+    a.set_state(snap)                                        # and back in time on the same engine
+    a.rollout(6, 4, 9)
+    np.testing.assert_array_equal(a.obs(), want["obs"])
