@@ -117,6 +117,10 @@ typedef struct mt_config {
   float radius;                 /* target hemisphere radius, reference 51.3                      */
   float dh_table[MT_MAX_DOF * 4]; /* rows (a, alpha_rad, d, theta_offset_rad), manytor.py:42-48 */
   int32_t return_ring;          /* slots of MT_F_RETURN_RING per env, 0..MT_MAX_RETURN_RING (0 = none) */
+  int32_t obs_frame;            /* row of joints_coordinates the observation is measured from: -dof..dof-1, Python   */
+                                /* indexing; the reference uses [2] = -2, the elbow (manytor.py:143)                 */
+  int32_t ee_frame;             /* row the pickup test uses; reference [3] = -1, the end effector (manytor.py:162).  */
+                                /* The ground test looks at the z of both rows (manytor.py:191).  Row 0 = the origin */
   int32_t reserved;             /* must be 0                                                     */
 } mt_config;
 

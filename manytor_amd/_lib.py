@@ -65,6 +65,8 @@ class MtConfig(C.Structure):
         ("radius", C.c_float),
         ("dh_table", C.c_float * (MT_MAX_DOF * 4)),
         ("return_ring", C.c_int32),
+        ("obs_frame", C.c_int32),
+        ("ee_frame", C.c_int32),
         ("reserved", C.c_int32),
     ]
 

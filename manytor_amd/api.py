@@ -305,7 +305,7 @@ class Environment:
 
     def __init__(self, obj_number=10, index=0, *, rng="numpy", seed=0x5EED, device=0, dh_table=REF_DH_TABLE,
                  substeps=25, pickup_tol=8.0, radius=51.3, terminate_on_ground=False, keep_trajectory=True,
-                 viewer=None):
+                 viewer=None, obs_frame=-2, ee_frame=-1):
         if rng not in ("numpy", "device"):
             raise ValueError("rng must be 'numpy' or 'device'")
         self._viewer = ViewerLink(*viewer) if isinstance(viewer, (tuple, list)) else viewer
@@ -327,7 +327,7 @@ class Environment:
         self._step_idx = 0
         self._engine = StepEngine(1, obj_number, dh_table=dh_table, substeps=substeps, pickup_tol=pickup_tol,
                                   radius=radius, device=device, env_id_base=index,
-                                  terminate_on_ground=terminate_on_ground)
+                                  terminate_on_ground=terminate_on_ground, obs_frame=obs_frame, ee_frame=ee_frame)
         # the reference constructor leaves points/joints empty until reset() (manytor.py:136-137);
         # arm the device state at the zero pose so attribute reads are defined
         self._engine.reset(np.zeros((1, obj_number, 3), dtype=np.float32))

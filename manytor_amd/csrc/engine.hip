@@ -52,6 +52,8 @@ DhConst make_dh(const float* table, int dof) {
     t.ca[j] = (float)ca;
     t.off_deg[j] = (float)(off * 180.0 / M_PI);
   }
+  t.fo = dof >= 2 ? dof - 2 : 0;  // the reference's rows (manytor.py:143, :162); mt_create overrides them from mt_config
+  t.fe = dof - 1;
   return t;
 }
 
@@ -158,10 +160,23 @@ void launch_trace_d(mt_handle h, const StepArgs& args, float* trace, bool sample
     default: break;                  \
   }
 
+template <int D>
+void launch_step_frames_d(mt_handle h, const StepArgs& args, bool sample) {
+  const dim3 g = grid_for(args.n), b(kBlock);
+  if (sample)
+    hipLaunchKernelGGL((step_kernel<RtTableF<D>, true, 0, false, 0>), g, b, 0, h->stream, args);
+  else
+    hipLaunchKernelGGL((step_kernel<RtTableF<D>, false, 0, false, 0>), g, b, 0, h->stream, args);
+}
+
 // One env step of the envs `args` describes (the whole batch, or one env of it: args_for_env); `trace` is the
 // matching view of the sub-step trace buffer or NULL.
 void launch_step(mt_handle h, const StepArgs& args, float* trace, bool sample) {
   if (trace) MT_DISPATCH_D(h->D, launch_trace_d, h, args, trace, sample);  // first: it needs the previous pose
+  if (h->custom_frames) {
+    MT_DISPATCH_D(h->D, launch_step_frames_d, h, args, sample);
+    return;
+  }
   if (h->static_kind == 1) return launch_step_t<Ref4Table, false>(h, args, sample);
   if (h->static_kind == 2) return launch_step_t<Dh7Table, false>(h, args, sample);
   MT_DISPATCH_D(h->D, launch_step_d, h, args, sample);
@@ -325,6 +340,8 @@ int mt_create(mt_handle* out, const mt_config* cfg) {
   MT_REQUIRE(nullptr, cfg->env_id_base >= 0, "env_id_base must be >= 0");
   MT_REQUIRE(nullptr, cfg->return_ring >= 0 && cfg->return_ring <= MT_MAX_RETURN_RING, "return_ring must be in 0..64");
   MT_REQUIRE(nullptr, cfg->reserved == 0, "mt_config.reserved must be 0");
+  MT_REQUIRE(nullptr, cfg->obs_frame >= -cfg->dof && cfg->obs_frame < cfg->dof, "obs_frame must be in -dof..dof-1");
+  MT_REQUIRE(nullptr, cfg->ee_frame >= -cfg->dof && cfg->ee_frame < cfg->dof, "ee_frame must be in -dof..dof-1");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
     (void)hipGetLastError();
@@ -440,7 +457,16 @@ int mt_create(mt_handle* out, const mt_config* cfg) {
   a.inv_sm1 = 1.0f / (float)(cfg->substeps - 1);
   a.flags = cfg->flags;
   a.dh = make_dh(cfg->dh_table, h->D);
-  h->static_kind = (cfg->flags & (MT_FLAG_NO_SPECIALIZE | MT_FLAG_DH_IN_LDS)) ? 0 : match_static(a.dh, h->D);
+  a.dh.fo = (cfg->obs_frame + h->D) % h->D;
+  a.dh.fe = (cfg->ee_frame + h->D) % h->D;
+  // other rows than the reference's last two: the runtime-table kernel with runtime frames (RtTableF), one env per lane
+  h->custom_frames = !(a.dh.fo == h->D - 2 && a.dh.fe == h->D - 1);
+  if (h->custom_frames) {
+    h->lds_table = false;
+    h->split = 0;
+    h->prefetch = false;
+  }
+  h->static_kind = ((cfg->flags & (MT_FLAG_NO_SPECIALIZE | MT_FLAG_DH_IN_LDS)) || h->custom_frames) ? 0 : match_static(a.dh, h->D);
   if (h->static_kind == 1 && !h->prefetch_forced) h->prefetch = true;
 #undef MT_HIP_C
   *out = h;
@@ -467,7 +493,7 @@ int mt_destroy(mt_handle h) {
 const char* mt_step_kernel_name(mt_handle h) {
   if (!h) return "";
   const char* tbl = h->static_kind == 1 ? "Ref4Table" : (h->static_kind == 2 ? "Dh7Table" : nullptr);
-  std::string table = tbl ? tbl : "RtTable<" + std::to_string(h->D) + ">";
+  std::string table = tbl ? tbl : (h->custom_frames ? "RtTableF<" : "RtTable<") + std::to_string(h->D) + ">";
   if (h->trig == 0 && !h->lds_table && h->split)
     h->kernel_name = "step_split_kernel<" + table + ", L=" + std::to_string(h->split) + ">";
   else
@@ -760,7 +786,7 @@ int mt_rollout_fused(mt_handle h, int n_steps, uint64_t seed, uint32_t step_idx0
   if (n_steps == 0) return MT_OK;
   // The fused kernel implements the default trigonometry only; the measured alternatives run the same thing as a
   // sequence of launches.
-  const bool fusable = h->trig == 0 && !h->lds_table && !h->trace;
+  const bool fusable = h->trig == 0 && !h->lds_table && !h->trace && !h->custom_frames;
   if (!fusable) {
     for (int s = 0; s < n_steps; ++s) {
       int rc = mt_step_random(h, seed, step_idx0 + (uint32_t)s);

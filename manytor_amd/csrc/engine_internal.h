@@ -32,6 +32,7 @@ struct mt_engine {
   bool is_reset = false;
   int trig = 0;          // 0 recurrence, 1 polynomial sincos per sub-step, 2 hardware trig per sub-step
   bool lds_table = false;
+  bool custom_frames = false;  // obs_frame / ee_frame are not the reference's last two rows: RtTableF kernels
   int split = 0;          // step_split_kernel<..., L>: one env over L = 2 or 4 lanes (0 = one env per lane)
   bool prefetch_forced = false;
   bool prefetch = false;  // step_kernel<..., PF = kPrefetch>: target loads requested ahead of the kinematics

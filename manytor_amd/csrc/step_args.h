@@ -18,6 +18,7 @@ struct DhConst {
   float sa[MT_MAX_DOF];       // sin(alpha)
   float ca[MT_MAX_DOF];       // cos(alpha)
   float off_deg[MT_MAX_DOF];  // theta offset, degrees
+  int32_t fo, fe;             // rows of joints_coordinates used for the observation / for pickup (0 = the origin row)
 };
 
 struct StepArgs {

@@ -63,7 +63,7 @@ class StepEngine:
 
     def __init__(self, n_envs, obj_number=10, dh_table=REF_DH_TABLE, substeps=25, pickup_tol=8.0, radius=51.3,
                  device=0, env_id_base=0, terminate_on_ground=False, hw_trig=False, dh_in_lds=False,
-                 direct_trig=False, specialize=True, ablate=0, return_ring=4, trace=False):
+                 direct_trig=False, specialize=True, ablate=0, return_ring=4, trace=False, obs_frame=-2, ee_frame=-1):
         self._lib = L.load()
         table = np.asarray(dh_table, dtype=np.float64)
         if table.ndim != 2 or table.shape[1] != 4:
@@ -90,6 +90,8 @@ class StepEngine:
         cfg.pickup_tol = float(pickup_tol)
         cfg.radius = float(radius)
         cfg.return_ring = int(return_ring)
+        cfg.obs_frame = int(obs_frame)      # rows of joints_coordinates: observation from [-2], pickup from [-1] in the
+        cfg.ee_frame = int(ee_frame)        # reference (manytor.py:143, :162); selectable for other arms
         cfg.reserved = 0
         self.return_ring_slots = int(return_ring)
         self.has_trace = bool(trace)

@@ -35,9 +35,9 @@ def load():
         dp, u8p, i32p = C.POINTER(C.c_double), C.POINTER(C.c_uint8), C.POINTER(C.c_int32)
         lib.mto_step.restype = None
         lib.mto_step.argtypes = [C.c_int64, C.c_int, C.c_int, C.c_int, C.c_double, dp, dp, dp, u8p, dp, dp, dp, i32p, u8p,
-                                 dp, dp, dp, C.c_int]
+                                 dp, dp, dp, C.c_int, C.c_int, C.c_int]
         lib.mto_observe.restype = None
-        lib.mto_observe.argtypes = [C.c_int64, C.c_int, C.c_int, dp, dp, dp, u8p, dp, C.c_int]
+        lib.mto_observe.argtypes = [C.c_int64, C.c_int, C.c_int, dp, dp, dp, u8p, dp, C.c_int, C.c_int]
         lib.mto_max_threads.restype = C.c_int
         _lib = lib
     return _lib
@@ -50,13 +50,15 @@ def _p(a, t):
 class COracle:
     """N lock-stepped envs on the C restatement; mirrors BatchOracle (manytor.py:125-260 semantics)."""
 
-    def __init__(self, n_envs, obj_number, table=None, substeps=25, pickup_tol=8.0, radius=51.3, threads=0):
+    def __init__(self, n_envs, obj_number, table=None, substeps=25, pickup_tol=8.0, radius=51.3, threads=0,
+                 obs_frame=-2, ee_frame=-1):
         from .manytor_oracle import REF_DH_TABLE
         self.lib = load()
         self.n, self.k = int(n_envs), int(obj_number)
         self.table = np.ascontiguousarray(REF_DH_TABLE if table is None else table, dtype=np.float64)
         self.dof = self.table.shape[0]
         assert 2 <= self.dof <= 8 and 1 <= self.k <= 32
+        self.fo, self.fe = obs_frame % self.dof, ee_frame % self.dof     # rows of joints_coordinates (Python indexing)
         self.substeps, self.pickup_tol, self.radius = int(substeps), float(pickup_tol), float(radius)
         self.threads = int(threads) or min(self.lib.mto_max_threads(), os.cpu_count() or 1)
         self.goals = np.zeros((self.n, self.dof))
@@ -82,7 +84,8 @@ class COracle:
     def get_observations(self):
         obs = np.empty((self.n, 3 * self.k))
         self.lib.mto_observe(self.n, self.dof, self.k, _p(self.table, C.c_double), _p(self.goals, C.c_double),
-                             _p(self.points, C.c_double), _p(self.alive_u8, C.c_uint8), _p(obs, C.c_double), self.threads)
+                             _p(self.points, C.c_double), _p(self.alive_u8, C.c_uint8), _p(obs, C.c_double), self.threads,
+                             self.fo)
         return obs
 
     def step(self, actions):
@@ -94,6 +97,7 @@ class COracle:
                           _p(self.goals, C.c_double), _p(self.points, C.c_double), _p(self.alive_u8, C.c_uint8),
                           _p(self.total_reward, C.c_double), _p(act, C.c_double), _p(obs2, C.c_double),
                           _p(reward, C.c_int32), _p(done, C.c_uint8), _p(self.joints_coordinates, C.c_double),
-                          _p(self.ground_margin, C.c_double), _p(self.pickup_margin, C.c_double), self.threads)
+                          _p(self.ground_margin, C.c_double), _p(self.pickup_margin, C.c_double), self.threads,
+                          self.fo, self.fe)
         self.ground_hit = reward == -1
         return obs2, reward.astype(np.int64), done.astype(bool)

@@ -98,9 +98,12 @@ class ScalarEnv:
     """One environment, restated loop by loop (no rendering, no trajectory)."""
 
     def __init__(self, obj_number=10, table=REF_DH_TABLE, substeps=REF_SUBSTEPS,
-                 pickup_tol=REF_PICKUP_TOL, radius=REF_RADIUS):
+                 pickup_tol=REF_PICKUP_TOL, radius=REF_RADIUS, obs_frame=-2, ee_frame=-1):
         self.table = np.asarray(table, dtype=np.float64)
         self.dof = self.table.shape[0]
+        # rows of joints_coordinates the reference hard-codes: observation from [2] = [-2] (manytor.py:143), pickup
+        # from [3] = [-1] (:162), ground test on both (:191); selectable for other arms (SURVEY 8(f) rank 2)
+        self.obs_frame, self.ee_frame = obs_frame, ee_frame
         self.obj_number = obj_number
         self.substeps = substeps
         self.pickup_tol = pickup_tol
@@ -131,7 +134,7 @@ class ScalarEnv:
 
     # manytor.py:141-153 ; measured from joints_coordinates[-2] (the "elbow")
     def get_observations(self):
-        jc = self.joints_coordinates[-2]
+        jc = self.joints_coordinates[self.obs_frame]
         obs = []
         for p in range(self.obj_number):
             if not self.alives[p]:
@@ -146,7 +149,7 @@ class ScalarEnv:
 
     # manytor.py:155-173 ; measured from joints_coordinates[-1] (end effector)
     def is_done(self):
-        ee = self.joints_coordinates[-1]
+        ee = self.joints_coordinates[self.ee_frame]
         for p in range(self.obj_number):
             if all(math.isclose(ee[a], self.points[p, a], abs_tol=self.pickup_tol) for a in range(3)):
                 self.alives[p] = False
@@ -164,7 +167,7 @@ class ScalarEnv:
         for k in range(self.substeps):
             self.goals = route[k, :]
             self.joints_coordinates = joints_coordinates(self.goals, self.table)
-            if self.joints_coordinates[-2, 2] < 0 or self.joints_coordinates[-1, 2] < 0:
+            if self.joints_coordinates[self.obs_frame, 2] < 0 or self.joints_coordinates[self.ee_frame, 2] < 0:
                 ground = True
         obs2 = self.get_observations()
         reward = 0
@@ -250,7 +253,8 @@ class BatchOracle:
     joints_coordinates (N,D,3)."""
 
     def __init__(self, n_envs, obj_number, table=REF_DH_TABLE, substeps=REF_SUBSTEPS,
-                 pickup_tol=REF_PICKUP_TOL, radius=REF_RADIUS, dtype=np.float64):
+                 pickup_tol=REF_PICKUP_TOL, radius=REF_RADIUS, dtype=np.float64, obs_frame=-2, ee_frame=-1):
+        self.obs_frame, self.ee_frame = obs_frame, ee_frame    # rows of joints_coordinates, see ScalarEnv
         self.n = int(n_envs)
         self.k = int(obj_number)
         self.table = np.asarray(table, dtype=np.float64)
@@ -281,12 +285,12 @@ class BatchOracle:
     def get_observations(self):
         dead = ~self.alives
         self.points[dead] = 0.0                         # manytor.py:148
-        return observe(self.joints_coordinates[:, -2], self.points, self.alives)
+        return observe(self.joints_coordinates[:, self.obs_frame], self.points, self.alives)
 
     def is_done(self):
         """manytor.py:155-173.  Also records the distance of every axis test
         from its threshold in ``pickup_margin``."""
-        ee = self.joints_coordinates[:, -1]
+        ee = self.joints_coordinates[:, self.ee_frame]
         delta = np.abs(ee[:, None, :] - self.points)   # (N,K,3)
         hit = np.all(delta <= self.pickup_tol, axis=-1)
         self.pickup_margin = np.min(np.abs(delta - self.pickup_tol), axis=-1)
@@ -306,8 +310,8 @@ class BatchOracle:
         for k in range(self.substeps):
             pose = actions if k == self.substeps - 1 else start + k * step
             jc = batch_joints_coordinates(pose, self.table, self.dtype)
-            z2 = jc[:, -2, 2]
-            z3 = jc[:, -1, 2]
+            z2 = jc[:, self.obs_frame, 2]
+            z3 = jc[:, self.ee_frame, 2]
             ground |= (z2 < 0) | (z3 < 0)
             margin = np.minimum(margin, np.minimum(np.abs(z2), np.abs(z3)))
         self.goals = actions.copy()

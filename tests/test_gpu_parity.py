@@ -35,10 +35,11 @@ def mo():
 class Lockstep:
     """Drive a StepEngine and a BatchOracle with the same inputs; compare every output every step."""
 
-    def __init__(self, m, mo, n, k, table=None, substeps=25, **kw):
+    def __init__(self, m, mo, n, k, table=None, substeps=25, obs_frame=-2, ee_frame=-1, **kw):
         table = m.REF_DH_TABLE if table is None else table
-        self.eng = m.StepEngine(n, k, dh_table=table, substeps=substeps, **kw)
-        self.ora = mo.BatchOracle(n, k, table=np.asarray(table), substeps=substeps)
+        self.fo, self.fe = obs_frame, ee_frame
+        self.eng = m.StepEngine(n, k, dh_table=table, substeps=substeps, obs_frame=obs_frame, ee_frame=ee_frame, **kw)
+        self.ora = mo.BatchOracle(n, k, table=np.asarray(table), substeps=substeps, obs_frame=obs_frame, ee_frame=ee_frame)
         self.n, self.k = n, k
         self.valid = np.ones(n, dtype=bool)      # envs whose discrete state is still comparable
         self.guarded = 0
@@ -52,7 +53,7 @@ class Lockstep:
         np.testing.assert_array_equal(self.eng.points(), p32)
         assert np.all(self.eng.goals() == 0) and np.all(self.eng.total_reward() == 0) and self.eng.alives().all()
         np.testing.assert_allclose(self.eng.joints_coordinates(), self.ora.joints_coordinates, atol=POS_TOL)
-        np.testing.assert_allclose(self.eng.ee(), self.ora.joints_coordinates[:, -1], atol=POS_TOL)
+        np.testing.assert_allclose(self.eng.ee(), self.ora.joints_coordinates[:, self.fe], atol=POS_TOL)
 
     def step(self, actions):
         e, o = self.eng, self.ora
@@ -65,9 +66,9 @@ class Lockstep:
         np.testing.assert_array_equal(e.goals(), np.asarray(actions, dtype=np.float32).reshape(self.n, -1))
         jc = e.joints_coordinates()
         assert np.abs(jc - o.joints_coordinates).max() <= POS_TOL
-        assert np.abs(e.ee() - o.joints_coordinates[:, -1]).max() <= POS_TOL
+        assert np.abs(e.ee() - o.joints_coordinates[:, self.fe]).max() <= POS_TOL
         if v.any():
-            assert_obs_close(e.obs()[v], obs_ref[v], o.joints_coordinates[v, -2], pre_points[v], pre_alive[v])
+            assert_obs_close(e.obs()[v], obs_ref[v], o.joints_coordinates[v, self.fo], pre_points[v], pre_alive[v])
         # discrete outputs under the guard band
         pick_m = np.where(pre_alive, o.pickup_margin, np.inf).min(axis=1)
         risky = (o.ground_margin < GUARD) | (pick_m < GUARD)
@@ -367,6 +368,49 @@ def test_other_joint_counts(m, mo, dof):
     ls.reset(rng.uniform(-20, 20, size=(512, 4, 3)))
     for t in range(5):
         ls.step(rng.randint(-180, 180, size=(512, dof)))
+
+
+@pytest.mark.parametrize("dof,obs_frame,ee_frame", [(4, 1, -1), (4, -1, -1), (5, -1, 2), (7, 0, -3), (3, -2, -2), (8, 3, 6)])
+def test_selectable_observation_and_pickup_frames(m, mo, dof, obs_frame, ee_frame):
+    """the rows of joints_coordinates the reference hard-codes -- observation from [2]
+    (manytor.py:143), pickup from [3] (:162), ground test on both (:191) -- as constructor arguments (Python indexing,
+    row 0 = the origin), in lock step with the oracle given the same rows; fused requests fall back to per-step launches."""
+    rng = np.random.RandomState(100 * dof + obs_frame + 10 * ee_frame)
+    if dof == 4:
+        table = np.array(m.REF_DH_TABLE)
+    else:
+        table = np.column_stack([rng.uniform(0, 10, dof), rng.choice([-np.pi / 2, 0, np.pi / 2, 0.4], dof),
+                                 rng.uniform(2, 15, dof), rng.choice([0, -np.pi / 2, 0.25], dof)])
+    n = 777
+    ls = Lockstep(m, mo, n, 5, table=table, obs_frame=obs_frame, ee_frame=ee_frame)
+    assert "RtTableF" in ls.eng.step_kernel_name()
+    ls.reset(rng.uniform(-25, 25, size=(n, 5, 3)))
+    for t in range(6):
+        ls.step(rng.randint(-180, 180, size=(n, dof)))
+    # row 0 is the origin: its z is exactly 0, i.e. ON the ground-test threshold, so with it every env sits inside the
+    # guard band by construction and only the continuous outputs are compared (the device says z < 0 is false, like numpy)
+    assert ls.compared > 0 or 0 in (obs_frame % dof, ee_frame % dof)
+    # the standalone passes and the random-action / fused entry points use the same rows
+    a, b = ls.eng, m.StepEngine(n, 5, dh_table=table, obs_frame=obs_frame, ee_frame=ee_frame)
+    b.set_state(a.get_state())
+    a.rollout(4, 3, 0)
+    b.rollout_fused(4, 3, 0)
+    for f in ("F_GOALS", "F_OBS", "F_REWARD", "F_DONE", "F_ALIVE", "F_EE", "F_TOTAL_REWARD"):
+        np.testing.assert_array_equal(a.get(getattr(m.lib, f)), b.get(getattr(m.lib, f)), err_msg=f)
+    obs_step = a.obs().copy()
+    a.observe()
+    alive = a.alives()
+    stay = np.repeat(alive, 3, axis=1)
+    np.testing.assert_allclose(a.obs()[stay], obs_step[stay], atol=2e-3)
+
+
+def test_default_frames_are_the_reference_rows(m):
+    eng = m.StepEngine(100, 3, obs_frame=2, ee_frame=3)          # the reference's literal rows, non-negative spelling
+    assert "RtTableF" not in eng.step_kernel_name() and "Ref4Table" in eng.step_kernel_name() + "Ref4Table"
+    with pytest.raises(ValueError):
+        m.StepEngine(10, 3, obs_frame=4)
+    with pytest.raises(ValueError):
+        m.StepEngine(10, 3, ee_frame=-5)
 
 
 def test_substeps_and_tolerance_parameters(m, mo):
