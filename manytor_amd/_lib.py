@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG_DIR, "libmanytor_hip.so")
+# MT_LIB_OVERRIDE: load another build of the SAME library (tools/sanitize_host.sh points it at the ASan/UBSan build)
+LIB_PATH = os.environ.get("MT_LIB_OVERRIDE") or os.path.join(PKG_DIR, "libmanytor_hip.so")
 
 MT_MAX_DOF = 8
 MT_MAX_TARGETS = 32

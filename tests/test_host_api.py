@@ -95,7 +95,7 @@ int main(void) {
     exe = tmp_path / "abi"
     libdir = os.path.dirname(_lib.LIB_PATH)
     subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
-                    "-L", libdir, "-l:libmanytor_hip.so", f"-Wl,-rpath,{libdir}"], check=True)
+                    _lib.LIB_PATH, f"-Wl,-rpath,{libdir}"], check=True)
     out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.strip().split("|")
     assert out[0] == str(lib.mt_version()) and out[1] == "invalid call order"
     assert int(out[2]) == _lib.MT_ERR_INVALID_ARG and "struct_size" in out[3]
