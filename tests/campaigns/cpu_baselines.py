@@ -14,7 +14,7 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import manytor_oracle as mo  # noqa: E402
 from oracle import philox_ref as px  # noqa: E402
 

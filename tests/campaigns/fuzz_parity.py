@@ -3,7 +3,7 @@
 integer / fractional / huge actions, kernel variants) stepped in lock step with the CPU oracle, using the same
 comparator and tolerances as tests/test_gpu_parity.py.  Run on the GPU box for as long as you like:
 
-    python tools/fuzz_parity.py --minutes 5 --seed 1
+    python tests/campaigns/fuzz_parity.py --minutes 5 --seed 1
 """
 import argparse
 import os
@@ -12,7 +12,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import manytor_amd as m  # noqa: E402

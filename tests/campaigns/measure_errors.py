@@ -6,7 +6,7 @@ import sys
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import manytor_amd as m  # noqa: E402
 from oracle import manytor_oracle as mo  # noqa: E402
 
