@@ -206,15 +206,23 @@ StepArgs args_for_env(mt_handle h, int64_t env) {
   return a;
 }
 
+template <int D, bool RANDOM, bool ONLY_DONE>
+void launch_reset_k(mt_handle h, const StepArgs& args) {
+  const size_t lds = RANDOM ? (size_t)3 * args.K * kBlock * sizeof(float) : 0;  // staging columns of the drawn targets
+  if (lds > 65536)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&reset_kernel<D, RANDOM, ONLY_DONE>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((reset_kernel<D, RANDOM, ONLY_DONE>), grid_for(args.n), dim3(kBlock), lds, h->stream, args,
+                     h->cfg.radius);
+}
 template <int D>
 void launch_reset_d(mt_handle h, const StepArgs& args, int mode) {  // 0 given points, 1 random, 2 random only-done
-  const dim3 g = grid_for(args.n), b(kBlock);
   if (mode == 0)
-    hipLaunchKernelGGL((reset_kernel<D, false, false>), g, b, 0, h->stream, args, h->cfg.radius);
+    launch_reset_k<D, false, false>(h, args);
   else if (mode == 1)
-    hipLaunchKernelGGL((reset_kernel<D, true, false>), g, b, 0, h->stream, args, h->cfg.radius);
+    launch_reset_k<D, true, false>(h, args);
   else
-    hipLaunchKernelGGL((reset_kernel<D, true, true>), g, b, 0, h->stream, args, h->cfg.radius);
+    launch_reset_k<D, true, true>(h, args);
 }
 
 template <int D>

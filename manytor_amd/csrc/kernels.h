@@ -955,18 +955,21 @@ __global__ __launch_bounds__(64) void done_bits_word_kernel(const uint8_t* done,
   if (threadIdx.x == 0) done_bits[word] = bits;
 }
 
-// One rejection-sampling candidate of manytor.py:229-239 from one Philox block.
-// Contraction is off so that every op rounds once, exactly as the numpy
-// restatement (oracle/philox_ref.py) does.
+// One rejection-sampling candidate of manytor.py:229-239: half HALF of a Philox block (philox.h: two candidates
+// per block).  Contraction is off so that every op rounds once, exactly as the numpy restatement
+// (oracle/philox_ref.py) does.
+template <int HALF>
 __device__ __forceinline__ bool target_candidate(const u32x4& w, float radius, float& x, float& y, float& z) {
 #pragma clang fp contract(off)
+  uint32_t fx, fy, fz;
+  candidate_fields<HALF>(w, fx, fy, fz);
   const float r2 = 2.0f * radius;
   const float rr = radius * radius;
-  const float tx = r2 * u01(w.x);
-  const float ty = r2 * u01(w.y);
+  const float tx = r2 * u21(fx);
+  const float ty = r2 * u21(fy);
   x = tx - radius;
   y = ty - radius;
-  z = radius * u01(w.z);
+  z = radius * u21(fz);
   const float xx = x * x, yy = y * y, zz = z * z;
   const float sxy = xx + yy;
   const float n2 = sxy + zz;
@@ -974,15 +977,20 @@ __device__ __forceinline__ bool target_candidate(const u32x4& w, float radius, f
 }
 
 // Rejection-sample K targets for one env (manytor.py:229-239) and hand each accepted one to `put(k, x, y, z)`.
-// The draw loop is bounded; the tail branch is unreachable in practice (acceptance pi/6 per draw).
+// Candidates are taken in the order (block 0, half 0), (block 0, half 1), (block 1, half 0), ...
+// The draw loop is bounded; the tail branch is unreachable in practice (acceptance pi/6 per candidate).
 template <class Put>
 __device__ __forceinline__ void draw_targets(uint64_t seed, uint64_t env_id, uint32_t episode, int K, float radius,
                                              Put&& put) {
   int cnt = 0;
-  for (uint32_t draw = 0; draw < 4096u && cnt < K; ++draw) {
-    const u32x4 w = stream_block(seed, env_id, kTagTarget, episode, draw);
+  for (uint32_t blk = 0; blk < 2048u && cnt < K; ++blk) {
+    const u32x4 w = stream_block(seed, env_id, kTagTarget, episode, blk);
     float x, y, z;
-    if (target_candidate(w, radius, x, y, z)) {
+    if (target_candidate<0>(w, radius, x, y, z)) {
+      put(cnt, x, y, z);
+      ++cnt;
+    }
+    if (cnt < K && target_candidate<1>(w, radius, x, y, z)) {
       put(cnt, x, y, z);
       ++cnt;
     }
@@ -1043,13 +1051,19 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(const StepArgs a, float r
     if (RANDOM) {
       // manytor.py:229-239: uniform in the cube, keep z >= 0 and |p| <= radius.  z is drawn from
       // [0, R) directly (same conditional law).  fp32, one rounding per op, mirrored by oracle/philox_ref.py.
+      // Envs of one wave accept their k-th target at different candidates, so storing from inside the draw loop
+      // would write partial lines of different rows per instruction.  The accepted targets are parked in this
+      // thread's LDS column ([3K][kBlock] floats, conflict-free) and written out row by row afterwards.
+      extern __shared__ float stage[];
+      float* col = stage + threadIdx.x;
       const uint64_t seed = ((uint64_t)a.seed_hi << 32) | a.seed_lo;
       draw_targets(seed, (uint64_t)(a.env_base + i), episode, a.K, radius, [&](int k, float x, float y, float z) {
-        float* row = a.points + (int64_t)(3 * k) * ld;
-        row[i] = x;
-        (row + ld)[i] = y;
-        (row + 2 * ld)[i] = z;
+        float* cell = col + 3 * k * kBlock;
+        cell[0] = x;
+        cell[kBlock] = y;
+        cell[2 * kBlock] = z;
       });
+      for (int r = 0; r < 3 * a.K; ++r) (a.points + (int64_t)r * ld)[i] = col[r * kBlock];
     }
   }
   if ((threadIdx.x & 63) == 0) a.done_bits[i >> 6] = 0ull;  // every env of the wave has done == 0 now

@@ -27,8 +27,10 @@ __host__ __device__ __forceinline__ uint32_t mulhi32(uint32_t a, uint32_t b) {
 __host__ __device__ __forceinline__ u32x4 philox4x32_10(u32x4 c, uint32_t k0, uint32_t k1) {
 #pragma unroll
   for (int r = 0; r < 10; ++r) {
-    const uint32_t hi0 = mulhi32(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
-    const uint32_t hi1 = mulhi32(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+    const uint64_t p0 = (uint64_t)0xD2511F53u * (uint64_t)c.x;  // one 32x32->64 multiply per product
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * (uint64_t)c.z;
+    const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+    const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
     c = u32x4{hi1 ^ c.y ^ k0, lo1, hi0 ^ c.w ^ k1, lo0};
     k0 += 0x9E3779B9u;
     k1 += 0xBB67AE85u;
@@ -53,7 +55,23 @@ __host__ __device__ __forceinline__ float action_from_word_digit1(uint32_t w) {
   return (float)mulhi32(w * 360u, 360u) - 180.0f;
 }
 
-// u in [0,1) with 24 bits
-__host__ __device__ __forceinline__ float u01(uint32_t w) { return (float)(w >> 8) * 5.9604644775390625e-08f; }
+// u in [0,1) from a 21-bit integer.  One Philox block (128 bits) is cut into six 21-bit fields, i.e. the three
+// coordinates of TWO rejection-sampling candidates:
+//   candidate 0: x, y, z fields = top 21 bits of words 0, 1, 2
+//   candidate 1: x, y, z fields = (low 11 bits of word 0, 1, 2) << 10 | bits [31:22], [21:12], [11:2] of word 3
+// All fields are disjoint bit ranges of the block, so the six uniforms are independent.
+__host__ __device__ __forceinline__ float u21(uint32_t v) { return (float)v * 4.76837158203125e-07f; }  // 2^-21
+template <int HALF>
+__host__ __device__ __forceinline__ void candidate_fields(const u32x4& w, uint32_t& fx, uint32_t& fy, uint32_t& fz) {
+  if (HALF == 0) {
+    fx = w.x >> 11;
+    fy = w.y >> 11;
+    fz = w.z >> 11;
+  } else {
+    fx = ((w.x & 0x7FFu) << 10) | (w.w >> 22);
+    fy = ((w.y & 0x7FFu) << 10) | ((w.w >> 12) & 0x3FFu);
+    fz = ((w.z & 0x7FFu) << 10) | ((w.w >> 2) & 0x3FFu);
+  }
+}
 
 }  // namespace mt

@@ -15,9 +15,14 @@ Stream definitions (key = (seed_lo, seed_hi)):
             joint j < 4 : float(mulhi32(w_j, 360)) - 180                    (digit 0 of word j)
             joint j >= 4: float(mulhi32(lo32(w_{j-4} * 360), 360)) - 180    (digit 1 of word j-4)
             -> integer degrees in [-180, 180)
-  targets : tag 2, major = episode index, minor = draw index (0,1,2,...)
-            u01(w) = (w >> 8) * 2^-24
-            x = 2R*u01(w0) - R ; y = 2R*u01(w1) - R ; z = R*u01(w2)   (fp32, one rounding per op)
+  targets : tag 2, major = episode index, minor = block index (0,1,2,...); every block yields TWO candidates,
+            taken in the order (block 0, half 0), (block 0, half 1), (block 1, half 0), ...: six disjoint
+            21-bit fields of the 128-bit block,
+              half 0: fx, fy, fz = w0 >> 11, w1 >> 11, w2 >> 11
+              half 1: fx = (w0 & 0x7FF) << 10 | w3 >> 22 ; fy = (w1 & 0x7FF) << 10 | (w3 >> 12) & 0x3FF ;
+                      fz = (w2 & 0x7FF) << 10 | (w3 >> 2) & 0x3FF
+            u21(f) = f * 2^-21
+            x = 2R*u21(fx) - R ; y = 2R*u21(fy) - R ; z = R*u21(fz)   (fp32, one rounding per op)
             accept iff (x*x + y*y) + z*z <= R*R                     (fp32, one rounding per op)
             (z is drawn from [0,R) directly: conditioning the reference's
              uniform(-R,R) on z >= 0, manytor.py:232, gives the same law.)
@@ -74,6 +79,17 @@ def sample_actions(seed, env_ids, step_idx, dof):
     return out
 
 
+def candidate_fields(w):
+    """The six 21-bit fields of one Philox block (4 uint32 arrays) as two (fx, fy, fz) triples."""
+    w0, w1, w2, w3 = (np.asarray(v, dtype=np.uint32) for v in w)
+    lowmask, ten = np.uint32(0x7FF), np.uint32(0x3FF)
+    half0 = (w0 >> np.uint32(11), w1 >> np.uint32(11), w2 >> np.uint32(11))
+    half1 = (((w0 & lowmask) << np.uint32(10)) | (w3 >> np.uint32(22)),
+             ((w1 & lowmask) << np.uint32(10)) | ((w3 >> np.uint32(12)) & ten),
+             ((w2 & lowmask) << np.uint32(10)) | ((w3 >> np.uint32(2)) & ten))
+    return half0, half1
+
+
 def sample_targets(seed, env_ids, episode_idx, obj_number, radius):
     """(N, K, 3) float32 targets by per-env rejection sampling.  `episode_idx`: one index for all envs or one per env
     (envs re-armed on the device run on their own episode counters)."""
@@ -85,20 +101,21 @@ def sample_targets(seed, env_ids, episode_idx, obj_number, radius):
     rr = r * r
     out = np.zeros((n, obj_number, 3), dtype=np.float32)
     cnt = np.zeros(n, dtype=np.int64)
-    draw = 0
-    scale = np.float32(2.0 ** -24)
+    blk = 0
+    scale = np.float32(2.0 ** -21)
     while (cnt < obj_number).any():
-        w = philox4x32_10(lo, hi, episode_idx, np.uint64(draw), seed & 0xFFFFFFFF, seed >> 32)
-        u = [(w[j] >> np.uint32(8)).astype(np.float32) * scale for j in range(3)]
-        x = r2 * u[0] - r
-        y = r2 * u[1] - r
-        z = r * u[2]
-        n2 = (x * x + y * y) + z * z
-        ok = (n2 <= rr) & (cnt < obj_number)
-        idx = np.nonzero(ok)[0]
-        out[idx, cnt[idx], 0] = x[idx]
-        out[idx, cnt[idx], 1] = y[idx]
-        out[idx, cnt[idx], 2] = z[idx]
-        cnt[idx] += 1
-        draw += 1
+        w = philox4x32_10(lo, hi, episode_idx, np.uint64(blk), seed & 0xFFFFFFFF, seed >> 32)
+        for fields in candidate_fields(w):
+            u = [f.astype(np.float32) * scale for f in fields]
+            x = r2 * u[0] - r
+            y = r2 * u[1] - r
+            z = r * u[2]
+            n2 = (x * x + y * y) + z * z
+            ok = (n2 <= rr) & (cnt < obj_number)
+            idx = np.nonzero(ok)[0]
+            out[idx, cnt[idx], 0] = x[idx]
+            out[idx, cnt[idx], 1] = y[idx]
+            out[idx, cnt[idx], 2] = z[idx]
+            cnt[idx] += 1
+        blk += 1
     return out
