@@ -458,6 +458,32 @@ def test_device_rng_streams_bit_exact(m):
     np.testing.assert_array_equal(e7.actions(), px.sample_actions(42, np.arange(300, dtype=np.uint64), 5, 7))
 
 
+@pytest.mark.parametrize("k", [1, 21, 22, 32])
+def test_device_target_draw_every_k(m, k):
+    """reset_kernel parks the accepted targets in a [3K][256] LDS tile before writing them out: 21 -> 22 targets
+    crosses the 64 KiB default limit for dynamic LDS, 32 is the largest K (96 KiB).  Ragged last block, and the re-arm
+    of finished envs only (mt_reset_done) through the same tile."""
+    from oracle import philox_ref as px
+    n = 1000 + k
+    ids = np.arange(n, dtype=np.uint64)
+    eng = m.StepEngine(n, k, dh_table=m.DH7_TABLE if k == 22 else m.REF_DH_TABLE, radius=51.3)
+    eng.reset_random(seed=77, episode=2)
+    np.testing.assert_array_equal(eng.points(), px.sample_targets(77, ids, 2, k, 51.3))
+    # finish every third env by hand (all targets picked), then re-arm only those
+    before = eng.points().copy()
+    fin = np.arange(n) % 3 == 0
+    eng.set(m.lib.F_ALIVE, np.where(fin[:, None], False, eng.alives()).astype(np.uint8))
+    eng.check_done()                    # may also pick a target sitting at the zero-pose end-effector (K = 1: finishes)
+    fin2 = eng.done()
+    assert fin2[fin].all() and fin2.sum() < fin.sum() + n // 50
+    eng.reset_done(seed=77)
+    expect = before.copy()
+    expect[fin2] = px.sample_targets(77, ids[fin2], 3, k, 51.3)     # their own episode counter advanced 2 -> 3
+    np.testing.assert_array_equal(eng.points(), expect)
+    assert not eng.done().any() and eng.alives()[fin2].all()
+    np.testing.assert_array_equal(eng.episodes(), np.where(fin2, 3, 2))
+
+
 def test_step_random_equals_sample_then_step(m):
     n, k = 10000, 7
     a, b = m.StepEngine(n, k), m.StepEngine(n, k)
