@@ -301,6 +301,13 @@ def main():
                     "sub-steps, 2 also skip the observation math")
     args = ap.parse_args()
 
+    # The contract is ONE JSON line on stdout.  Native libraries loaded below write there too (RCCL prints a version
+    # banner when its first multi-rank communicator is built, gloo its connection report), so fd 1 is pointed at
+    # stderr for the rest of the run and the line goes to the original stdout at the end.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
 
@@ -337,8 +344,28 @@ def main():
                        specialize=not args.no_specialize, ablate=args.ablate)
     # The engine keeps its own stream: step launches, the RCCL gather and the resets are all enqueued on it through the
     # C ABI, in program order; torch only brackets the timed regions (barrier + torch.cuda.synchronize()).
+    gather_fallback = None
     if world > 1 and not args.rehearsal:
-        D.connect(raw, rank, world)                             # mt_comm_unique_id -> store -> mt_comm_init (RCCL)
+        err = None
+        try:
+            D.connect(raw, rank, world)                         # mt_comm_unique_id -> store -> mt_comm_init (RCCL)
+        except Exception as e:                                  # noqa: BLE001 -- reported below, on every rank
+            err = e
+        # Contingency (never taken where mt_comm_init works): if ANY rank could not join the communicator, all ranks
+        # drop it and gather through the torch.distributed process group instead, and the JSON line says so.
+        flag = torch.tensor([1 if err is not None else 0], dtype=torch.int32,
+                            device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if int(flag.item()):
+            print(f"[bench] rank {rank}: mt_comm_init path unavailable ({err}); gathering through torch.distributed "
+                  f"({backend}) instead", file=sys.stderr)
+            if err is None:
+                raw.comm_destroy()
+            if backend == "nccl":
+                D.attach_torch_gather(raw, n_total, rank, world)
+            else:
+                D.attach_gloo_gather(raw, n_total, rank, world)
+            gather_fallback = f"mt_comm_init failed on at least one rank ({err if err is not None else 'another rank'})"
     elif world > 1:
         D.attach_gloo_gather(raw, n_total, rank, world)         # rehearsal stand-in for the RCCL gather
     eng = TimedEngine(raw)
@@ -415,7 +442,10 @@ def main():
         if world > 1:
             collective = ("gloo all-gather (REHEARSAL on one device, not RCCL)" if args.rehearsal else
                           "RCCL all-gather of returns per episode through mt_gather_returns (C ABI), straight from the arena")
-            if os.environ.get("MT_RCCL_LIB", "").endswith("libfake_rccl.so"):
+            if gather_fallback:
+                collective = f"FALLBACK: torch.distributed ({backend}) all-gather of the returns per episode, in line; " \
+                             f"{gather_fallback}"
+            elif os.environ.get("MT_RCCL_LIB", "").endswith("libfake_rccl.so"):
                 collective = "mt_gather_returns (C ABI) over the shared-memory STAND-IN for librccl (tests/fake_rccl): " \
                              "a rehearsal of the N > 1 product path on one GPU, not a scaling number"
         out = {
@@ -481,7 +511,7 @@ def main():
                     "frac_actual_of_hbm_peak": b2a * n2 / (us * 1e-6) / 1e9 / HBM_PEAK_GBS}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(table, args.targets)
-        print(json.dumps(out), flush=True)
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
 
     raw.close()
     if world > 1:

@@ -81,6 +81,50 @@ def connect(engine, rank=None, world_size=None, group=None):
     return engine
 
 
+# ---- contingency for bench.py: the gather through torch.distributed's own RCCL process group ----------------------
+def attach_torch_gather(engine, n_total: int, rank: int, world_size: int, group=None):
+    """If mt_comm_init cannot be set up on a node, bench.py still has to produce its N > 1 line: the returns are then
+    all-gathered by torch.distributed (backend nccl = RCCL) on the process group torchrun created, device to device,
+    straight from the arena view.  The engine is moved onto torch's current stream so that its launches and the
+    collective stay in program order.  Same result layout as mt_gather_returns (global env order, ragged shards
+    included); no overlap with the next episode."""
+    import torch
+    import torch.distributed as dist
+
+    from . import _lib as L
+    counts = [shard_range(n_total, r, world_size)[1] for r in range(world_size)]
+    if engine.n_envs != counts[rank]:
+        raise ValueError(f"rank {rank} holds {engine.n_envs} envs, expected {counts[rank]}")
+    cmax, equal = max(counts), len(set(counts)) == 1
+    engine.use_torch_stream()
+    dev = f"cuda:{engine.device}"
+    stage = None if equal else (torch.zeros(cmax, dtype=torch.float32, device=dev),
+                                torch.empty(world_size * cmax, dtype=torch.float32, device=dev))
+
+    def gather_returns(out=None, field=None, row=0):
+        src = engine.device_tensor(L.F_TOTAL_REWARD if field is None else field)
+        src = src if src.dim() == 1 else src[row]
+        if out is None:
+            out = torch.empty(n_total, dtype=torch.float32, device=dev)
+        if equal:
+            dist.all_gather_into_tensor(out, src, group=group)
+        else:
+            send, recv = stage
+            send[: src.numel()].copy_(src)
+            dist.all_gather_into_tensor(recv, send, group=group)
+            off = 0
+            for r, c in enumerate(counts):
+                out[off: off + c].copy_(recv[r * cmax: r * cmax + c])
+                off += c
+        return out
+
+    engine.gather_returns = gather_returns
+    engine.gather_begin = gather_returns
+    engine.gather_wait = lambda host=False: 0.0 if host else None
+    engine.total_envs = lambda: n_total
+    return engine
+
+
 # ---- CPU stand-in for tests and bench.py --rehearsal (not the product path) --------------------------------------
 def gloo_gather_returns(local_returns, n_total: int, group=None):
     """All-gather per-env returns (1-D CPU tensor of this rank's shard) into one (n_total,) tensor in global env order

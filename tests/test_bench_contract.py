@@ -15,9 +15,8 @@ def test_bench_prints_one_contract_line():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5",
                           "--envs-per-gpu", "262144", "--no-secondary"], capture_output=True, text=True, timeout=300, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
-    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
-    assert len(lines) == 1
-    d = json.loads(lines[0])
+    assert out.stdout.count("\n") == 1 and out.stdout.endswith("\n")     # nothing but the line (native chatter -> stderr)
+    d = json.loads(out.stdout)
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert key in d, key

@@ -251,6 +251,40 @@ def test_gather_returns_without_and_with_a_one_rank_rccl_communicator(m):
     eng.close()
 
 
+def test_bench_contingency_gather_through_a_torch_process_group(m):
+    """bench.py's fallback when mt_comm_init is unavailable on a node (manytor_amd.distributed.attach_torch_gather):
+    a one-rank nccl (= RCCL) process group of torch.distributed gathers straight from the arena view, ordered with the
+    engine's launches on torch's stream."""
+    import socket
+
+    import torch
+    import torch.distributed as dist
+
+    from manytor_amd import distributed as D
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        n = 30011
+        eng = m.StepEngine(n, 7)
+        D.attach_torch_gather(eng, n, 0, 1)
+        eng.reset_random(3, 0)
+        eng.rollout(6, 3, 0)
+        out = eng.gather_begin()
+        want = eng.total_reward()
+        eng.reset_random(3, 1)                               # same stream: ordered behind the collective
+        assert eng.gather_wait(host=True) == 0.0
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(out.cpu().numpy(), want)
+        assert np.abs(want).max() > 0 and eng.total_envs() == n
+        with pytest.raises(ValueError):
+            D.attach_torch_gather(m.StepEngine(100, 7), 300, 0, 2)       # shard size does not match the layout
+    finally:
+        dist.destroy_process_group()
+
+
 def test_checkpoint_and_resume_is_bit_identical(m):
     """SURVEY 5 (checkpoint / resume): the reference's state is a handful of attributes (manytor.py:131-139);
     get_state() / set_state() carry the same on and off the device, also into a fresh engine."""

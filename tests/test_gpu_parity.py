@@ -565,7 +565,7 @@ def test_shard_invariance(m):
     whole = m.StepEngine(n, k)
     whole.reset_random(5, 0)
     whole.rollout(6, 5, 0)
-    for world in (2, 8):
+    for world in (2, 4, 8):
         parts = []
         for r in range(world):
             base, cnt = shard_range(n, r, world)
