@@ -374,6 +374,9 @@ def main():
 
     def fence():
         if world > 1:
+            # drain this rank's own queues first (incl. an exchange still running on the engine's side stream), so that
+            # the barrier's collective never shares the device with one of another communicator
+            raw.sync()
             dist.barrier()
         torch.cuda.synchronize()
 

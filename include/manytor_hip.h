@@ -235,8 +235,9 @@ MT_API int mt_gather_returns(mt_handle h, int field, int row, float* dst, int64_
  * next may overwrite it), the all-gather runs on a side stream of the handle, and the call returns at once -- steps and
  * resets queued afterwards overlap with the exchange over xGMI.  mt_gather_returns_wait orders the handle's stream
  * behind the last begun gather; with host_wait != 0 it also blocks the calling thread until dst is complete and, if
- * elapsed_ms is not NULL, reports the device time the exchange took.  dst must not be read, and the communicator not
- * destroyed, before that.  mt_sync also waits for a begun gather. */
+ * elapsed_ms is not NULL, reports the device time the exchange took (if mt_sync has already waited for it: the time
+ * of that last completed exchange).  dst must not be read, and the communicator not destroyed, before that.  mt_sync
+ * also waits for a begun gather. */
 MT_API int mt_gather_returns_begin(mt_handle h, int field, int row, float* dst, int64_t dst_elems);
 MT_API int mt_gather_returns_wait(mt_handle h, int host_wait, float* elapsed_ms);
 /* Total number of envs over all ranks of the communicator (n_envs without one). */

@@ -329,13 +329,14 @@ int mt_gather_returns_begin(mt_handle h, int field, int row, float* dst, int64_t
 
 int mt_gather_returns_wait(mt_handle h, int host_wait, float* elapsed_ms) {
   MT_REQUIRE(nullptr, h != nullptr, "handle is NULL");
-  if (elapsed_ms) *elapsed_ms = 0.f;
+  if (elapsed_ms) *elapsed_ms = host_wait ? h->last_gather_ms : 0.f;  // nothing pending: the last completed exchange
   if (!h->gather_pending) return MT_OK;
   MT_ON_DEVICE(h, h->cfg.device);
   MT_HIP(h, hipStreamWaitEvent(h->stream, h->ev_g1, 0));
   if (host_wait) {
     MT_HIP(h, hipEventSynchronize(h->ev_g1));
-    if (elapsed_ms) MT_HIP(h, hipEventElapsedTime(elapsed_ms, h->ev_g0, h->ev_g1));
+    MT_HIP(h, hipEventElapsedTime(&h->last_gather_ms, h->ev_g0, h->ev_g1));
+    if (elapsed_ms) *elapsed_ms = h->last_gather_ms;
     h->gather_pending = false;
   }
   return MT_OK;

@@ -531,6 +531,7 @@ int mt_sync(mt_handle h) {
   MT_HIP(h, hipStreamSynchronize(h->stream));
   if (h->gather_pending) {  // a gather begun on the side stream is part of "everything queued on this handle"
     MT_HIP(h, hipStreamSynchronize(h->side_stream));
+    MT_HIP(h, hipEventElapsedTime(&h->last_gather_ms, h->ev_g0, h->ev_g1));
     h->gather_pending = false;
   }
   return MT_OK;

@@ -43,6 +43,7 @@ struct mt_engine {
   hipEvent_t ev_snap = nullptr, ev_g0 = nullptr, ev_g1 = nullptr;
   float* snap = nullptr;
   bool gather_pending = false;
+  float last_gather_ms = 0.f;  // device time of the last exchange that was waited for (mt_gather_returns_wait / mt_sync)
   std::string err;
   std::string kernel_name;  // mt_step_kernel_name
 };
