@@ -372,12 +372,20 @@ def main():
     L = max(1, min(args.episode_len, args.steps))               # >= 1 gather inside every timed region
     loop = EpisodeLoop(eng, args.seed, L, fused=args.fused, overlap=not args.sync_gather)
 
+    # Barrier of the timed regions at N > 1: a shared-memory barrier between the ranks of the node (microseconds); the
+    # process group's collective barrier (tens of microseconds inside a 0.9 ms region) only if that cannot be set up.
+    host_barrier = D.make_host_barrier(rank, world) if world > 1 else None
+
     def fence():
         if world > 1:
-            # drain this rank's own queues first (incl. an exchange still running on the engine's side stream), so that
-            # the barrier's collective never shares the device with one of another communicator
+            # drain this rank's own queues first (incl. an exchange still running on the engine's side stream): the
+            # barrier is then passed only when every rank's device work is complete, and a collective barrier never
+            # shares the device with an exchange of the other communicator
             raw.sync()
-            dist.barrier()
+            if host_barrier is not None:
+                host_barrier.wait()
+            else:
+                dist.barrier()
         torch.cuda.synchronize()
 
     # ---- pre-warm: >= PREWARM_S of step launches, so that the timed regions run at the steady clock ------------
@@ -463,7 +471,11 @@ def main():
                        "gather_mode": "in line on the engine's stream" if args.sync_gather else
                                       "overlapped: snapshot + exchange on the engine's side stream (mt_gather_returns_begin)",
                        "timing": "median over `repeats` regions of exactly `steps` steps, each bracketed by barrier + "
-                                 "torch.cuda.synchronize(), max over ranks"},
+                                 "torch.cuda.synchronize(), max over ranks",
+                       "barrier": "none (one rank)" if world == 1 else
+                                  ("device drained, then a shared-memory barrier between the node's ranks "
+                                   "(manytor_amd.distributed.HostBarrier)" if host_barrier is not None else
+                                   "device drained, then torch.distributed barrier")},
             "ms_per_step_min": float(regions.min()) / args.steps * 1e3,
             "ms_per_step_max": float(regions.max()) / args.steps * 1e3,
             "gather_us": gather_ms * 1e3 / max(1, gathers),
@@ -517,6 +529,8 @@ def main():
         os.write(json_fd, (json.dumps(out) + "\n").encode())
 
     raw.close()
+    if host_barrier is not None:
+        host_barrier.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -81,6 +81,105 @@ def connect(engine, rank=None, world_size=None, group=None):
     return engine
 
 
+# ---- a cheap barrier between the ranks of one node -----------------------------------------------------------------
+class HostBarrier:
+    """Barrier between the processes of ONE node through a small file in /dev/shm: every rank owns a 64-byte slot
+    holding the number of barriers it has entered (single writer, monotonic, one aligned 8-byte store), and leaves
+    wait() once every slot has reached its own count.  A few microseconds, against the tens of a collective-based
+    ``dist.barrier()``; bench.py brackets its timed regions with it (one process per GPU, one node, as launched by
+    torch.distributed.run).  Purely host-side: the caller synchronises its device before entering."""
+
+    SLOT = 8                                   # int64 per slot = one 64-byte line
+
+    def __init__(self, path: str, rank: int, world_size: int, create: bool):
+        import mmap
+
+        import numpy as np
+        self.path, self.rank, self.world, self.epoch = path, int(rank), int(world_size), 0
+        size = 64 * self.world
+        flags = os.O_RDWR | (os.O_CREAT | os.O_EXCL if create else 0)
+        fd = os.open(path, flags, 0o600)
+        try:
+            if create:
+                os.ftruncate(fd, size)         # zero-filled
+            elif os.fstat(fd).st_size != size:
+                raise RuntimeError(f"{path}: unexpected size")
+            self._map = mmap.mmap(fd, size)
+        finally:
+            os.close(fd)
+        self._slots = np.ndarray((self.world, self.SLOT), dtype=np.int64, buffer=self._map)
+
+    def unlink(self):
+        """Remove the name (the mapping stays valid for every process that has it open)."""
+        try:
+            os.unlink(self.path)
+        except FileNotFoundError:
+            pass
+
+    def wait(self, timeout_s: float = 300.0):
+        import time
+        self.epoch += 1
+        self._slots[self.rank, 0] = self.epoch
+        col = self._slots[:, 0]
+        spins, t0 = 0, None
+        while int(col.min()) < self.epoch:
+            spins += 1
+            if spins & 0x3FF == 0:             # be polite if ranks outnumber cores, and never spin for ever
+                time.sleep(0)
+                now = time.monotonic()
+                t0 = now if t0 is None else t0
+                if now - t0 > timeout_s:
+                    raise TimeoutError(f"HostBarrier: rank {self.rank} waited {timeout_s:.0f} s at barrier {self.epoch}: "
+                                       f"counts {col.tolist()}")
+
+    def close(self):
+        self._slots = None
+        try:
+            self._map.close()
+        except (BufferError, ValueError):
+            pass
+
+
+def make_host_barrier(rank: int, world_size: int, group=None):
+    """Set up a HostBarrier over the ranks of the process group, or return None (on EVERY rank) if any rank cannot --
+    e.g. the ranks do not share /dev/shm because they sit on different nodes.  Collective."""
+    import secrets
+
+    import torch
+    import torch.distributed as dist
+    box = [f"/dev/shm/manytor_barrier_{os.getpid()}_{secrets.token_hex(6)}" if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0, group=group)
+    path, bar, err = box[0], None, None
+    on_gpu = dist.get_backend(group) == "nccl"
+
+    def agree(failed: bool) -> bool:
+        flag = torch.tensor([1 if failed else 0], dtype=torch.int32, device="cuda" if on_gpu else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+        return bool(int(flag.item()))
+
+    try:
+        if rank == 0:
+            bar = HostBarrier(path, rank, world_size, create=True)
+    except Exception as e:                     # noqa: BLE001 -- every rank learns about it below
+        err = e
+    if agree(err is not None):
+        return None
+    try:
+        if rank != 0:
+            bar = HostBarrier(path, rank, world_size, create=False)
+    except Exception as e:                     # noqa: BLE001
+        err = e
+    failed = agree(err is not None)
+    if rank == 0 and bar is not None:
+        bar.unlink()                           # everybody who could has it mapped; no file is left behind
+    if failed:
+        if bar is not None:
+            bar.close()
+        return None
+    bar.wait()
+    return bar
+
+
 # ---- contingency for bench.py: the gather through torch.distributed's own RCCL process group ----------------------
 def attach_torch_gather(engine, n_total: int, rank: int, world_size: int, group=None):
     """If mt_comm_init cannot be set up on a node, bench.py still has to produce its N > 1 line: the returns are then

@@ -83,6 +83,62 @@ def test_gather_single_process_is_identity():
     assert torch.equal(D.gloo_gather_returns(t, 10), t)
 
 
+def _barrier_worker(rank, world, port, rounds, q):
+    import time
+    r, _, w = _init(rank, world, port)
+    bar = D.make_host_barrier(r, w)
+    assert bar is not None and not os.path.exists(bar.path)       # the name is gone once everybody has it mapped
+    slots = bar._slots
+    ok = True
+    for it in range(1, rounds + 1):
+        if (it + r) % 97 == 0:
+            time.sleep(0.002)                                      # a straggler, a different rank every time
+        slots[r, 1] = it                                           # "my work of round `it` is done"
+        bar.wait()
+        ok &= bool((slots[:, 1] >= it).all())                      # nobody left the barrier before everybody arrived
+    t0 = time.perf_counter()
+    for _ in range(200):
+        bar.wait()
+    us = (time.perf_counter() - t0) / 200 * 1e6
+    dist.barrier()
+    if r == 0:
+        q.put((ok, us))
+    else:
+        assert ok
+    bar.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_host_barrier_keeps_ranks_in_lockstep(world):
+    ok, us = _spawn(_barrier_worker, (2000,), world=world)
+    assert ok
+    assert us < 5000                                               # microseconds per barrier (loose: shared CI cores)
+
+
+def _barrier_unavailable_worker(rank, world, port, q):
+    r, _, w = _init(rank, world, port)
+    real = D.HostBarrier.__init__
+
+    def broken(self, path, rank_, world_, create):
+        if rank_ == 1:
+            raise OSError("no shared /dev/shm on this rank")
+        real(self, path, rank_, world_, create)
+    D.HostBarrier.__init__ = broken
+    bar = D.make_host_barrier(r, w)                                # one rank cannot attach => None on EVERY rank
+    dist.barrier()
+    if r == 0:
+        q.put(bar is None)
+    else:
+        assert bar is None
+    dist.destroy_process_group()
+
+
+def test_host_barrier_falls_back_on_every_rank_if_one_cannot_attach():
+    assert _spawn(_barrier_unavailable_worker, ()) is True
+    assert not [f for f in os.listdir("/dev/shm") if f.startswith("manytor_barrier_")]
+
+
 class _FakeEngine:
     """Stand-in for StepEngine in bench.EpisodeLoop: returns = number of steps since the last reset + global env id /
     1e6, gathered over gloo.  Lets the CPU check count what the GPU run would launch."""
