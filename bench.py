@@ -392,13 +392,24 @@ def main():
     prewarm = 0
     fence()
     t0 = time.perf_counter()
-    while time.perf_counter() - t0 < PREWARM_S:
+    ctrl_dev = "cuda" if backend == "nccl" else "cpu"
+
+    def rank0_says(flag):
+        """The pre-warm is time-based, but its chunks contain collectives (the gathers): every rank must run the same
+        number of them, so rank 0's clock decides for everybody."""
+        if world == 1:
+            return flag
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=ctrl_dev)
+        dist.broadcast(t, src=0)
+        return bool(int(t.item()))
+
+    while rank0_says(time.perf_counter() - t0 < PREWARM_S):
         loop.run(max(L, 200))
         prewarm += max(L, 200)
         torch.cuda.synchronize()
     est_s = (time.perf_counter() - t0) / prewarm * args.steps   # one region, estimated
     if world > 1:
-        t = torch.tensor([est_s], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        t = torch.tensor([est_s], dtype=torch.float64, device=ctrl_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         est_s = float(t.item())
     repeats = args.repeats or int(min(100, max(5, math.ceil(MIN_TIMED_S / max(est_s, 1e-6)))))
@@ -422,7 +433,7 @@ def main():
         gathers += gt
     regions = np.array(regions)
     if world > 1:
-        t = torch.tensor(regions, dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        t = torch.tensor(regions, dtype=torch.float64, device=ctrl_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)                # a region takes as long as its slowest rank
         regions = t.cpu().numpy()
     elapsed = float(np.median(regions))
