@@ -307,6 +307,9 @@ def main():
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
+    # multi-process GPU work on this pool needs dmabuf IPC (RCCL's hipIpcGetMemHandle fails with the legacy mode); the
+    # launcher normally exports it already
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
     import torch
     import torch.distributed as dist

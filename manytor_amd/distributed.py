@@ -16,6 +16,11 @@ from __future__ import annotations
 
 import os
 
+# RCCL shares device buffers between the processes of a node through IPC handles; on hosts whose driver only supports
+# dmabuf IPC the legacy mode fails with "hipIpcGetMemHandle: invalid argument".  Read when the HIP runtime starts, so it
+# has to be in the environment before the first device call; a value set by the launcher wins.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 
 def shard_range(n_total: int, rank: int, world_size: int):
     """(first global env id, number of envs) of `rank`: contiguous blocks, sizes differ by at most one."""
