@@ -241,7 +241,7 @@ void launch_joints_d(mt_handle h, float* out) {
 template <class Tbl, int L>
 void launch_rollout_split_t(mt_handle h, const RolloutArgs& r) {
   const int64_t per_block = kBlock / L;
-  const size_t lds = (size_t)3 * h->K * per_block * sizeof(float);
+  const size_t lds = (size_t)3 * h->K * per_block * sizeof(float) + (ActionTrigTable<Tbl>::value ? kTrigEntries * sizeof(SinCos) : 0);
   if (lds > 65536)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_split_kernel<Tbl, L>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -253,7 +253,8 @@ template <class Tbl>
 void launch_rollout_t(mt_handle h, const RolloutArgs& r) {
   if (h->split == 4) return launch_rollout_split_t<Tbl, 4>(h, r);
   if (h->split == 2) return launch_rollout_split_t<Tbl, 2>(h, r);
-  const size_t lds = (size_t)3 * h->K * kBlock * sizeof(float);  // 21.5 KB at K = 7, 96 KB at K = 32 (of 160 KB)
+  // 21.5 KB at K = 7, 96 KB at K = 32 (of 160 KB), + 3.6 KB for the action sin / cos table of the compile-time tables
+  const size_t lds = (size_t)3 * h->K * kBlock * sizeof(float) + (ActionTrigTable<Tbl>::value ? kTrigEntries * sizeof(SinCos) : 0);
   if (lds > 65536)  // above the default dynamic-LDS limit the kernel has to be told
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_kernel<Tbl>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

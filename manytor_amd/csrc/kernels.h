@@ -350,6 +350,61 @@ __device__ __forceinline__ void sincos_increment(const float (&st)[D], float (&s
   }
 }
 
+// Sines / cosines of a SAMPLED action (rollout kernels).  draw_action yields integer degrees in [-180, 180), and the
+// joint offsets of the compile-time tables are whole degrees in [-90, 0], so action + offset is one of the 450
+// integers -270 .. 179: the block fills an LDS table with sincos_deg of exactly those floats once per launch and every
+// step looks its D pairs up instead of evaluating D range reductions and polynomials (~30 instructions each, 8-11 %
+// of a rollout step).  Same function on the same float => the same bits as computing it in place.
+constexpr int kTrigBias = 270;
+constexpr int kTrigEntries = 450;
+struct SinCos {
+  float s, c;
+};
+template <class Tbl>
+struct ActionTrigTable {
+  static constexpr bool value = false;
+};
+template <>
+struct ActionTrigTable<Ref4Table> {
+  static constexpr bool value = true;
+};
+template <>
+struct ActionTrigTable<Dh7Table> {
+  static constexpr bool value = true;
+};
+template <class Tbl>
+constexpr bool whole_degree_offsets() {
+  for (int j = 0; j < Tbl::D; ++j) {
+    const float o = Tbl::off(j);
+    if (o != (float)(int)o || o < -90.f || o > 0.f) return false;
+  }
+  return true;
+}
+// all threads of the block, before anybody returns
+__device__ __forceinline__ void fill_action_trig(SinCos* trig) {
+  for (int idx = threadIdx.x; idx < kTrigEntries; idx += kBlock) {
+    float sv, cv;
+    sincos_deg((float)(idx - kTrigBias), sv, cv);
+    trig[idx] = SinCos{sv, cv};
+  }
+  __syncthreads();
+}
+template <class Tbl, bool TABLE>
+__device__ __forceinline__ void action_sincos(const Tbl& t, const float (&act)[Tbl::D], float (&sv)[Tbl::D],
+                                              float (&cv)[Tbl::D], const SinCos* trig) {
+#pragma unroll
+  for (int j = 0; j < Tbl::D; ++j) {
+    if constexpr (TABLE) {
+      static_assert(whole_degree_offsets<Tbl>(), "the table covers whole-degree offsets in [-90, 0] only");
+      const SinCos v = trig[(int)act[j] + ((int)Tbl::off(j) + kTrigBias)];
+      sv[j] = v.s;
+      cv[j] = v.c;
+    } else {
+      sincos_deg(act[j] + t.off(j), sv[j], cv[j]);
+    }
+  }
+}
+
 // The kinematic part of Environment.action (manytor.py:178-192) for one env: S poses on the straight line in
 // joint space from `g` (previous pose) to `act`.  Returns the elbow and end-effector positions at the final pose
 // and the minimum z of those two frames over all S poses (ground flag <=> zmin < 0).  Shared by step_kernel and
@@ -374,10 +429,11 @@ struct PoseCache {
   float zmin;        // min z of its last two frames
 };
 
-template <class Tbl, int TRIG, bool CACHED = false>
+template <class Tbl, int TRIG, bool CACHED = false, bool TABLE = false>
 __device__ __forceinline__ float route_kinematics(const Tbl& t, int S, float inv_sm1, const float (&g)[Tbl::D],
                                                   const float (&act)[Tbl::D], float (&el)[3], float (&e)[3],
-                                                  PoseCache<Tbl::D>* cache = nullptr, bool cache_valid = false) {
+                                                  PoseCache<Tbl::D>* cache = nullptr, bool cache_valid = false,
+                                                  const SinCos* trig = nullptr) {
   constexpr int D = Tbl::D;
   constexpr int JN = ZJoints<Tbl>::value;
   constexpr bool kSequential = (TRIG == 0 || TRIG == 5) && D >= 6;
@@ -422,8 +478,7 @@ __device__ __forceinline__ float route_kinematics(const Tbl& t, int S, float inv
     }
     // k = S-1: the action itself, full chain (positions are consumed by the caller), then the backward half
     float sB[D], cB[D], p[D][3];
-#pragma unroll
-    for (int j = 0; j < D; ++j) sincos_deg(act[j] + t.off(j), sB[j], cB[j]);
+    action_sincos<Tbl, TABLE>(t, act, sB, cB, trig);
     chain_all<Tbl>(sB, cB, t, p);
     pick_frames<Tbl>(t, p, el, e);
     zmin = fminf(zmin, fminf(el[2], e[2]));
@@ -448,8 +503,7 @@ __device__ __forceinline__ float route_kinematics(const Tbl& t, int S, float inv
 
   // k = S-1: the action itself, full chain (positions are consumed by the caller)
   float sA[D], cA[D], p[D][3];
-#pragma unroll
-  for (int j = 0; j < D; ++j) sincos_deg(act[j] + t.off(j), sA[j], cA[j]);
+  action_sincos<Tbl, TABLE>(t, act, sA, cA, trig);
   chain_all<Tbl>(sA, cA, t, p);
   pick_frames<Tbl>(t, p, el, e);
   zmin = fminf(el[2], e[2]);
@@ -697,11 +751,11 @@ __global__ __launch_bounds__(kBlock, (PF ? 1 : step_min_waves<Tbl, TRIG>())) voi
 // the env's sub-lanes at the end (lane = q * (64 / L) + e, so the partners sit 64 / L, 2 * 64 / L ... lanes apart).
 // Every sub-lane computes the endpoint sincos and the full chain at the final pose itself (it needs elbow and end
 // effector for its targets).  -(s * -sd) == s * sd exactly and min is order-free => the bits of route_kinematics.
-template <class Tbl, int L, bool CACHED>
+template <class Tbl, int L, bool CACHED, bool TABLE = false>
 __device__ __forceinline__ float route_kinematics_split(const Tbl& t, int S, float inv_sm1, const float (&g)[Tbl::D],
                                                         const float (&act)[Tbl::D], bool backward, float (&el)[3],
                                                         float (&e)[3], PoseCache<Tbl::D>* cache = nullptr,
-                                                        bool cache_valid = false) {
+                                                        bool cache_valid = false, const SinCos* trig = nullptr) {
   constexpr int D = Tbl::D;
   constexpr int JN = ZJoints<Tbl>::value;
   constexpr int EPW = 64 / L;
@@ -710,8 +764,7 @@ __device__ __forceinline__ float route_kinematics_split(const Tbl& t, int S, flo
 #pragma unroll
   for (int j = 0; j < D; ++j) st[j] = (act[j] - g[j]) * inv_sm1;
   float sA[D], cA[D], p3[D][3];
-#pragma unroll
-  for (int j = 0; j < D; ++j) sincos_deg(act[j] + t.off(j), sA[j], cA[j]);
+  action_sincos<Tbl, TABLE>(t, act, sA, cA, trig);
   chain_all<Tbl>(sA, cA, t, p3);
   pick_frames<Tbl>(t, p3, el, e);
   float sF[D], cF[D];
@@ -1089,9 +1142,16 @@ struct RolloutArgs {
 
 template <class Tbl>
 __global__ __launch_bounds__(kBlock) void rollout_kernel(const StepArgs a, const RolloutArgs r) {
-  extern __shared__ float tile[];  // [3K][kBlock]
+  extern __shared__ float tile[];  // [3K][kBlock] (+ the action sin / cos table for the compile-time tables)
   constexpr int D = Tbl::D;
+  constexpr bool kTable = ActionTrigTable<Tbl>::value;
   const Tbl t = TableMaker<Tbl>::make(a.dh);
+  const SinCos* trig = nullptr;
+  if constexpr (kTable) {
+    SinCos* w = reinterpret_cast<SinCos*>(tile + 3 * a.K * kBlock);
+    fill_action_trig(w);
+    trig = w;
+  }
   const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= a.n) return;  // no barrier below: every thread touches only its own LDS column
   const int64_t ld = a.ld;
@@ -1114,7 +1174,7 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(const StepArgs a, const
   for (int s = 0; s < r.T; ++s) {
     float act[D], el[3], e[3];
     draw_action<D>(seed, env_id, r.step0 + (uint32_t)s, act);
-    const float zmin = route_kinematics<Tbl, 0, true>(t, a.S, a.inv_sm1, g, act, el, e, &pose, pose_valid);
+    const float zmin = route_kinematics<Tbl, 0, true, kTable>(t, a.S, a.inv_sm1, g, act, el, e, &pose, pose_valid, trig);
     pose_valid = true;
     const bool ground = zmin < 0.f;
 
@@ -1190,11 +1250,18 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(const StepArgs a, const
 template <class Tbl, int L>
 __global__ __launch_bounds__(kBlock) void rollout_split_kernel(const StepArgs a, const RolloutArgs r) {
   static_assert(L == 2 || L == 4, "an env is spread over 2 or 4 lanes");
-  extern __shared__ float tile[];  // [3K][kBlock / L]
+  extern __shared__ float tile[];  // [3K][kBlock / L] (+ the action sin / cos table for the compile-time tables)
   constexpr int D = Tbl::D;
   constexpr int EPW = 64 / L;
   constexpr int EPB = kBlock / L;  // envs per block = columns of the tile
+  constexpr bool kTable = ActionTrigTable<Tbl>::value;
   const Tbl t = TableMaker<Tbl>::make(a.dh);
+  const SinCos* trig = nullptr;
+  if constexpr (kTable) {
+    SinCos* w = reinterpret_cast<SinCos*>(tile + 3 * a.K * EPB);
+    fill_action_trig(w);
+    trig = w;
+  }
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
   const uint32_t q = lane / EPW;
@@ -1228,7 +1295,7 @@ __global__ __launch_bounds__(kBlock) void rollout_split_kernel(const StepArgs a,
   for (int s = 0; s < r.T; ++s) {
     float act[D], el[3], e[3];
     draw_action<D>(seed, env_id, r.step0 + (uint32_t)s, act);
-    const float zmin = route_kinematics_split<Tbl, L, true>(t, a.S, a.inv_sm1, g, act, backward, el, e, &pose, pose_valid);
+    const float zmin = route_kinematics_split<Tbl, L, true, kTable>(t, a.S, a.inv_sm1, g, act, backward, el, e, &pose, pose_valid, trig);
     pose_valid = true;
     const bool ground = zmin < 0.f;
 
