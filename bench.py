@@ -262,34 +262,46 @@ def time_step_launches(m, n, table, radius, k, dev, seed, fused=False, steps=600
     return us, name
 
 
-def time_loaded_action_steps(m, n, table, radius, k, dev, seed, steps=600, episode_len=50):
+def time_loaded_action_steps(m, n, table, radius, k, dev, seed, steps=600, episode_len=50, chunk=10):
     """us per mt_step launch when the actions come from HBM, as with a policy in the loop (step_kernel<SAMPLE = false>:
     exactly SURVEY 8(d)'s byte model incl. the 4D-byte action read).  The actions of every step are written by
-    mt_sample_actions (a separate small launch, outside the laps), so the arms move as in the headline."""
+    mt_sample_actions (a separate small launch), so the arms move as in the headline.  HIP-event laps around chunks of
+    `chunk` (sample, step) pairs, minus laps around chunks of `chunk` sample launches alone: a lap around every single
+    launch would add the cost of its two event records to a 40 us kernel."""
     e = m.StepEngine(n, k, dh_table=table, radius=radius, device=dev)
-    t, laps = 0, 0
-    t0 = time.perf_counter()
-    for phase_steps in (None, steps):
-        if phase_steps is not None:
-            e.lap_times()
+    t = 0
+
+    def pairs(count, timed):
+        nonlocal t
         done = 0
-        while (phase_steps is None and time.perf_counter() - t0 < 0.15) or (phase_steps is not None and done < phase_steps):
+        while done < count:
             if t % episode_len == 0:
                 e.reset_random(seed, t // episode_len)
-            e.sample_actions(seed, t)
-            if phase_steps is not None:
+            seg = min(chunk, count - done, episode_len - t % episode_len)
+            if timed:
                 e.lap_begin()
-            e.step()
-            if phase_steps is not None:
+            for _ in range(seg):
+                e.sample_actions(seed, t)
+                e.step()
+                t += 1
+            if timed:
                 e.lap_end()
-                laps += 1
-            t += 1
-            done += 1
-            if phase_steps is None and t % 200 == 0:
-                e.sync()
-    us = sum(e.lap_times()) * 1e3 / laps
+            done += seg
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 0.15:
+        pairs(200, False)
+        e.sync()
+    e.lap_times()
+    pairs(steps, True)
+    us_pair = sum(e.lap_times()) * 1e3 / steps
+    for rep in range(steps // chunk):
+        e.lap_begin()
+        for j in range(chunk):
+            e.sample_actions(seed, rep * chunk + j)
+        e.lap_end()
+    us_sample = sum(e.lap_times()) * 1e3 / (steps // chunk * chunk)
     e.close()
-    return us
+    return us_pair - us_sample, us_sample
 
 
 def main():
@@ -553,13 +565,14 @@ def main():
                 "env_steps_per_s": n_local / (us * 1e-6), "us_per_step": us, "steps_per_launch": 50,
                 "note": "mt_rollout_fused: state stays in registers/LDS between steps, bit-identical results; "
                         "arithmetic-bound, so the per-step byte model does not apply"}}
-            us = time_loaded_action_steps(m, n_local, table, radius, args.targets, dev, args.seed)
+            us, us_sample = time_loaded_action_steps(m, n_local, table, radius, args.targets, dev, args.seed)
             out["secondary"]["loaded_action_step"] = {
-                "us_per_step": us, "env_steps_per_s": n_local / (us * 1e-6), "bytes_per_env_step": bpe,
+                "us_per_step": us, "sample_actions_us": us_sample,
+                "env_steps_per_s": n_local / (us * 1e-6), "bytes_per_env_step": bpe,
                 "frac_of_hbm_peak": bpe * n_local / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                 "note": "mt_step with the actions read from HBM (policy-in-the-loop shape, step_kernel<SAMPLE = false>): "
                         "the kernel that moves exactly the SURVEY 8(d) bytes; the actions are written by a separate "
-                        "mt_sample_actions launch outside the laps"}
+                        "mt_sample_actions launch whose own time (sample_actions_us) is subtracted"}
             # BASELINE.json's other single-GPU configurations and the pure-HBM point, same kernel path, short runs
             out["secondary"]["other_configs"] = {}
             for label, n2, tbl, rad in (("configs[1]: 65536 arms, 4-DoF", 65536, m.REF_DH_TABLE, 51.3),
