@@ -42,6 +42,7 @@ struct mt_engine {
   hipStream_t side_stream = nullptr;
   hipEvent_t ev_snap = nullptr, ev_g0 = nullptr, ev_g1 = nullptr;
   float* snap = nullptr;
+  bool reset_split = false;  // mt_reset_random / mt_reset_done of the whole batch: reset_split_kernel
   bool gather_pending = false;
   float last_gather_ms = 0.f;  // device time of the last exchange that was waited for (mt_gather_returns_wait / mt_sync)
   std::string err;

@@ -1122,6 +1122,99 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(const StepArgs a, float r
   if ((threadIdx.x & 63) == 0) a.done_bits[i >> 6] = 0ull;  // every env of the wave has done == 0 now
 }
 
+// reset with the draw of an env's targets spread over L lanes of a wave -- for batches so small that the kernel's time
+// is one wave per SIMD walking its ~13 Philox blocks one after the other (11-12 us at <= 65 536 arms, of which the
+// launch and the stores are about half).  Lane layout as in step_split_kernel (lane = q * (64 / L) + e).  Sub-lane q of an
+// env evaluates blocks q, q + L, q + 2 L, ...; in every round the accepted candidates are numbered in block order
+// across the env's sub-lanes (their counts travel by shuffle), so the K targets are exactly the first K accepted
+// candidates of draw_targets' sequential order: the same bits as reset_kernel.  The targets are parked in the env's
+// LDS column ([3K][kBlock / L]) and written out by the sub-lanes in turn; everything else is done by sub-lane 0.
+template <int D, bool ONLY_DONE, int L>
+__global__ __launch_bounds__(kBlock) void reset_split_kernel(const StepArgs a, float radius) {
+  static_assert(L == 2 || L == 4, "an env is spread over 2 or 4 lanes");
+  extern __shared__ float stage[];  // [3K][kBlock / L]
+  constexpr int EPW = 64 / L;
+  constexpr int EPB = kBlock / L;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  const uint32_t q = lane / EPW;
+  const uint32_t e = lane % EPW;
+  const int64_t first = (int64_t)wave * EPW;
+  if (first >= a.n) return;
+  const uint32_t env = (uint32_t)first + e;
+  const bool live = env < a.n;  // tail lanes shadow the last env (in their own column) and store nothing
+  const uint32_t i = live ? env : (uint32_t)(a.n - 1);
+  const int64_t ld = a.ld;
+  // every sub-lane reads what it needs of the old state first; sub-lane 0 overwrites it after the draw
+  const uint8_t dn = ONLY_DONE ? a.done[i] : (uint8_t)1;
+  const bool go = dn == 1;
+  const uint32_t old_episode = ONLY_DONE ? a.episodes[i] : 0u;
+  const float old_total = a.total_reward[i];
+  const uint32_t episode = ONLY_DONE ? old_episode + 1u : a.major;
+  float* col = stage + (threadIdx.x >> 6) * EPW + e;
+  const uint64_t seed = ((uint64_t)a.seed_hi << 32) | a.seed_lo;
+  const uint64_t env_id = (uint64_t)(a.env_base + i);
+  const int K = a.K;
+  auto put = [&](int k, float x, float y, float z) {
+    float* cell = col + 3 * k * EPB;
+    cell[0] = x;
+    cell[EPB] = y;
+    cell[2 * EPB] = z;
+  };
+  int cnt = go ? 0 : K;  // the same in all sub-lanes of an env, so they leave the loop together
+  for (uint32_t round = 0; round < 2048u / L && cnt < K; ++round) {
+    const u32x4 w = stream_block(seed, env_id, kTagTarget, episode, round * L + q);
+    float x0, y0, z0, x1, y1, z1;
+    const bool a0 = target_candidate<0>(w, radius, x0, y0, z0);
+    const bool a1 = target_candidate<1>(w, radius, x1, y1, z1);
+    const int mine = (a0 ? 1 : 0) + (a1 ? 1 : 0);
+    int before = 0, total = 0;
+#pragma unroll
+    for (int qq = 0; qq < L; ++qq) {
+      const int c = __shfl(mine, qq * EPW + (int)e);
+      total += c;
+      before += (qq < (int)q) ? c : 0;
+    }
+    const int k0 = cnt + before;
+    if (a0 && k0 < K) put(k0, x0, y0, z0);
+    const int k1 = k0 + (a0 ? 1 : 0);
+    if (a1 && k1 < K) put(k1, x1, y1, z1);
+    cnt += total;
+  }
+  if (q == 0)
+    for (; cnt < K; ++cnt) put(cnt, 0.f, 0.f, 0.5f * radius);  // unreachable in practice, as in draw_targets
+  __builtin_amdgcn_wave_barrier();  // the columns were written by the env's sub-lanes; a wave only touches its own
+  if (live && go)
+    for (int r = (int)q; r < 3 * K; r += L) (a.points + (int64_t)r * ld)[i] = col[r * EPB];
+  if (live && q == 0) {
+    if (ONLY_DONE && dn == 2) a.done[i] = 0;
+    if (go) {
+      float s[D], c[D], p[D][3];
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+        (a.goals + j * ld)[i] = 0.f;
+        sincos_deg(a.dh.off_deg[j], s[j], c[j]);
+      }
+      const RtTableF<D> t{a.dh};
+      chain_all<RtTableF<D>>(s, c, t, p);
+      float el0[3], e0[3];
+      pick_frames<RtTableF<D>>(t, p, el0, e0);
+#pragma unroll
+      for (int qq = 0; qq < 3; ++qq) (a.ee + qq * ld)[i] = e0[qq];
+      if (ONLY_DONE)
+        record_finished(a, i, old_episode, old_total);
+      else
+        a.last_return[i] = old_total;
+      a.total_reward[i] = 0.f;
+      a.reward[i] = 0;
+      a.done[i] = 0;
+      a.alive[i] = (K >= 32) ? 0xFFFFFFFFu : ((1u << K) - 1u);
+      a.episodes[i] = episode;
+    }
+  }
+  if (lane == 0) a.done_bits[first >> 6] = 0ull;  // every env of the word has done == 0 after this launch
+}
+
 // ---------------------------------------------------------------------------
 // rollout: T consecutive Environment.step()s with in-kernel random actions in ONE launch (the inner loop of
 // test_multi.py:19-21), optionally re-arming an env the moment it finishes.

@@ -458,12 +458,15 @@ def test_device_rng_streams_bit_exact(m):
     np.testing.assert_array_equal(e7.actions(), px.sample_actions(42, np.arange(300, dtype=np.uint64), 5, 7))
 
 
+@pytest.mark.parametrize("split", [0, 1])
 @pytest.mark.parametrize("k", [1, 21, 22, 32])
-def test_device_target_draw_every_k(m, k):
+def test_device_target_draw_every_k(m, k, split, monkeypatch):
     """reset_kernel parks the accepted targets in a [3K][256] LDS tile before writing them out: 21 -> 22 targets
     crosses the 64 KiB default limit for dynamic LDS, 32 is the largest K (96 KiB).  Ragged last block, and the re-arm
-    of finished envs only (mt_reset_done) through the same tile."""
+    of finished envs only (mt_reset_done) through the same tile.  split = 1: reset_split_kernel (an env's draw over 4
+    lanes, what small batches get by default), split = 0: one env per lane."""
     from oracle import philox_ref as px
+    monkeypatch.setenv("MT_RESET_SPLIT", str(split))
     n = 1000 + k
     ids = np.arange(n, dtype=np.uint64)
     eng = m.StepEngine(n, k, dh_table=m.DH7_TABLE if k == 22 else m.REF_DH_TABLE, radius=51.3)
@@ -482,6 +485,35 @@ def test_device_target_draw_every_k(m, k):
     np.testing.assert_array_equal(eng.points(), expect)
     assert not eng.done().any() and eng.alives()[fin2].all()
     np.testing.assert_array_equal(eng.episodes(), np.where(fin2, 3, 2))
+
+
+@pytest.mark.parametrize("n", [1, 63, 4097, 70000])
+def test_reset_split_kernel_equals_reset_kernel(m, n, monkeypatch):
+    """Every field after mt_reset_random and after mt_reset_done (ring, last return, episode counters, done bits
+    included) is the same whether the draw runs one env per lane or over 4 lanes per env."""
+    fields = ("F_GOALS", "F_POINTS", "F_ALIVE", "F_TOTAL_REWARD", "F_REWARD", "F_DONE", "F_DONE_BITS", "F_EE",
+              "F_EPISODES", "F_LAST_RETURN", "F_RETURN_RING")
+    outs = []
+    for split in (0, 1):
+        monkeypatch.setenv("MT_RESET_SPLIT", str(split))
+        eng = m.StepEngine(n, 5, pickup_tol=30.0, return_ring=3)
+        eng.reset_random(21, 4)
+        snap = [{f: eng.get(getattr(m.lib, f)) for f in fields}]
+        for rep in range(3):
+            eng.rollout(6, 21, 6 * rep)            # a wide pickup box: some envs finish
+            eng.reset_done(21)
+            snap.append({f: eng.get(getattr(m.lib, f)) for f in fields})
+        eng.rollout_fused(8, 21, 50, auto_reset=True)      # leaves done == 2 behind for the envs it re-armed itself
+        eng.reset_done(21)
+        snap.append({f: eng.get(getattr(m.lib, f)) for f in fields})
+        eng.reset_random(21, 9)
+        snap.append({f: eng.get(getattr(m.lib, f)) for f in fields})
+        outs.append(snap)
+        eng.close()
+    assert outs[0][1]["F_EPISODES"].max() > 4 or n < 64       # somebody did finish and was re-armed
+    for a, b in zip(*outs):
+        for f in fields:
+            np.testing.assert_array_equal(a[f], b[f], err_msg=f)
 
 
 def test_step_random_equals_sample_then_step(m):

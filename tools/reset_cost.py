@@ -27,8 +27,11 @@ def laps(eng, fn, reps):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--envs", type=int, default=1048576)
+    ap.add_argument("--reset-split", type=int, default=-1, help="force MT_RESET_SPLIT (0/1); default: the library's choice")
     a = ap.parse_args()
-    out = {"envs": a.envs}
+    if a.reset_split >= 0:
+        os.environ["MT_RESET_SPLIT"] = str(a.reset_split)
+    out = {"envs": a.envs, "reset_split": a.reset_split}
     for name, kw in (("4-DoF reference table", {}), ("7-DoF table", dict(dh_table=m.DH7_TABLE))):
         eng = m.StepEngine(a.envs, 7, **kw)
         eng.reset_random(1, 0)
