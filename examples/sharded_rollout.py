@@ -25,6 +25,9 @@ def main():
     cli.add_argument("--steps", type=int, default=50)                  # test_multi.py:8
     cli.add_argument("--targets", type=int, default=7)                 # test_multi.py:9
     cli.add_argument("--seed", type=lambda s: int(s, 0), default=0x5EED)
+    cli.add_argument("--stats-only", action="store_true",
+                     help="log the returns' sum / min / max over all ranks (mt_reduce_returns: five numbers per rank "
+                          "exchanged) instead of gathering every env's return")
     opt = cli.parse_args()
 
     rank, local_rank, world = D.init_process_group()                   # no-op for a single process
@@ -37,6 +40,12 @@ def main():
     began = time.perf_counter()
     for ep in range(opt.episodes):
         eng.rollout(opt.steps, opt.seed, ep * opt.steps)               # one launch per step, actions drawn in-kernel
+        if opt.stats_only:
+            st = eng.return_stats()                                    # collective, synchronous, 40 bytes per rank
+            if rank == 0:
+                print(f"episode {ep:3d}: {st['count']} envs, mean return {st['mean']:8.3f}, best {st['max']:4.0f}")
+            eng.reset_random(opt.seed, ep + 1)
+            continue
         if pending is not None:                                        # last episode's returns: complete by now
             eng.gather_wait(host=True)
             if rank == 0:
@@ -48,8 +57,9 @@ def main():
     eng.sync()
     wall = time.perf_counter() - began
     if rank == 0:
-        r = pending.cpu().numpy()
-        print(f"episode {opt.episodes - 1:3d}: {r.size} returns gathered, mean {r.mean():8.3f}, best {r.max():4.0f}")
+        if pending is not None:
+            r = pending.cpu().numpy()
+            print(f"episode {opt.episodes - 1:3d}: {r.size} returns gathered, mean {r.mean():8.3f}, best {r.max():4.0f}")
         total = opt.envs_total * opt.episodes * opt.steps
         print(f"{total} env-steps on {world} GPU(s) in {wall:.3f} s: {total / wall:.3e} env-steps/s")
     eng.close()

@@ -242,6 +242,17 @@ MT_API int mt_gather_returns_begin(mt_handle h, int field, int row, float* dst, 
 MT_API int mt_gather_returns_wait(mt_handle h, int host_wait, float* elapsed_ms);
 /* Total number of envs over all ranks of the communicator (n_envs without one). */
 MT_API int mt_comm_total_envs(mt_handle h, int64_t* total);
+/* Summary of a return row over ALL ranks without moving the row (what a learner logs per episode):
+ * sum / min / max of row `row` of `field` (as for mt_gather_returns), the number of envs, and how many of them have
+ * their done flag set.  Reduced on the device (double accumulation, fixed order: the same bits on every rank and from
+ * run to run), five numbers per rank exchanged over the communicator (all-gather), combined on the host.
+ * Synchronous on the handle's stream; collective when a communicator is attached. */
+typedef struct mt_return_stats {
+  double sum, min, max;
+  int64_t count; /* envs over all ranks */
+  int64_t done;  /* of which MT_F_DONE != 0 */
+} mt_return_stats;
+MT_API int mt_reduce_returns(mt_handle h, int field, int row, mt_return_stats* out);
 
 /* HIP-event timer on the handle's stream (wall-clock of test_multi.py:16-18, device side). */
 MT_API int mt_timer_start(mt_handle h);

@@ -52,6 +52,10 @@ class ManytorError(RuntimeError):
         self.status = status
 
 
+class MtReturnStats(C.Structure):
+    _fields_ = [("sum", C.c_double), ("min", C.c_double), ("max", C.c_double), ("count", C.c_int64), ("done", C.c_int64)]
+
+
 class MtConfig(C.Structure):
     _fields_ = [
         ("struct_size", C.c_int32),
@@ -112,6 +116,7 @@ PROTOTYPES = {
     "mt_gather_returns_begin": (C.c_int, [_HANDLE, C.c_int, C.c_int, C.c_void_p, C.c_int64]),
     "mt_gather_returns_wait": (C.c_int, [_HANDLE, C.c_int, C.POINTER(C.c_float)]),
     "mt_comm_total_envs": (C.c_int, [_HANDLE, C.POINTER(C.c_int64)]),
+    "mt_reduce_returns": (C.c_int, [_HANDLE, C.c_int, C.c_int, C.c_void_p]),
     "mt_timer_start": (C.c_int, [_HANDLE]),
     "mt_timer_stop": (C.c_int, [_HANDLE, C.POINTER(C.c_float)]),
     "mt_timer_lap_begin": (C.c_int, [_HANDLE]),

@@ -278,6 +278,40 @@ static int gather_on_stream(mt_handle h, const float* src, float* dst, int64_t d
   return MT_OK;
 }
 
+// Block partials of {sum, min, max, done count} over one return row: a fixed assignment of envs to threads and a fixed
+// tree inside the block, double accumulation -- the same bits whenever the same numbers come in.
+constexpr int kReduceBlocks = 256;
+struct ReducePartial {
+  double sum, min, max, done;
+};
+__global__ __launch_bounds__(kBlock) void reduce_returns_kernel(const float* __restrict__ src,
+                                                                const uint8_t* __restrict__ done, int64_t n,
+                                                                ReducePartial* __restrict__ out) {
+  __shared__ ReducePartial sh[kBlock];
+  ReducePartial p{0.0, 1.0e300, -1.0e300, 0.0};
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+    const double v = (double)src[i];
+    p.sum += v;
+    p.min = v < p.min ? v : p.min;
+    p.max = v > p.max ? v : p.max;
+    p.done += done[i] != 0 ? 1.0 : 0.0;
+  }
+  sh[threadIdx.x] = p;
+  __syncthreads();
+  for (int w = kBlock / 2; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) {
+      const ReducePartial o = sh[threadIdx.x + w];
+      ReducePartial& m = sh[threadIdx.x];
+      m.sum += o.sum;
+      m.min = o.min < m.min ? o.min : m.min;
+      m.max = o.max > m.max ? o.max : m.max;
+      m.done += o.done;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[blockIdx.x] = sh[0];
+}
+
 // A gather begun with mt_gather_returns_begin and not yet waited for: order `stream` behind it.
 static int order_behind_pending_gather(mt_handle h, hipStream_t stream) {
   if (h->gather_pending) MT_HIP(h, hipStreamWaitEvent(stream, h->ev_g1, 0));
@@ -294,6 +328,69 @@ int mt_gather_returns(mt_handle h, int field, int row, float* dst, int64_t dst_e
   rc = order_behind_pending_gather(h, h->stream);  // the two forms share the communicator and its staging buffer
   if (rc) return rc;
   return gather_on_stream(h, src, dst, dst_elems, h->stream);
+}
+
+int mt_reduce_returns(mt_handle h, int field, int row, mt_return_stats* out) {
+  MT_REQUIRE(nullptr, h != nullptr, "handle is NULL");
+  MT_REQUIRE(h, out != nullptr, "out is NULL");
+  int rc;
+  const float* src = gather_source(h, field, row, &rc);
+  if (!src) return rc;
+  MT_ON_DEVICE(h, h->cfg.device);
+  mt_comm* c = h->comm;
+  const int world = (c && c->world > 1) ? c->world : 1;
+  // device scratch: [kReduceBlocks] block partials, then [world + 1] per-rank records (slot `world` = this rank's)
+  const size_t bytes = sizeof(ReducePartial) * (size_t)(kReduceBlocks + world + 1);
+  ReducePartial* d = nullptr;
+  MT_HIP(h, hipMalloc(&d, bytes));
+  std::vector<ReducePartial> host((size_t)kReduceBlocks + (size_t)world);
+  auto body = [&]() -> int {
+    hipLaunchKernelGGL(reduce_returns_kernel, dim3(kReduceBlocks), dim3(kBlock), 0, h->stream, src, h->args.done, h->n, d);
+    MT_HIP(h, hipGetLastError());
+    MT_HIP(h, hipMemcpyAsync(host.data(), d, sizeof(ReducePartial) * kReduceBlocks, hipMemcpyDeviceToHost, h->stream));
+    MT_HIP(h, hipStreamSynchronize(h->stream));
+    ReducePartial mine{0.0, 1.0e300, -1.0e300, 0.0};
+    for (int b = 0; b < kReduceBlocks; ++b) {  // fixed order
+      const ReducePartial& p = host[(size_t)b];
+      mine.sum += p.sum;
+      mine.min = p.min < mine.min ? p.min : mine.min;
+      mine.max = p.max > mine.max ? p.max : mine.max;
+      mine.done += p.done;
+    }
+    ReducePartial all = mine;
+    int64_t count = h->n;
+    if (world > 1) {
+      Rccl* r = rccl();
+      if (!r) return fail(h, MT_ERR_UNSUPPORTED, "RCCL is not available: " + g_rccl.error);
+      rc = order_behind_pending_gather(h, h->stream);  // one communicator: never two exchanges in flight
+      if (rc) return rc;
+      ReducePartial* recs = d + kReduceBlocks;
+      MT_HIP(h, hipMemcpyAsync(recs + world, &mine, sizeof mine, hipMemcpyHostToDevice, h->stream));
+      static_assert(sizeof(ReducePartial) == 4 * sizeof(int64_t), "exchanged as four 64-bit words per rank");
+      MT_NCCL(h, r, r->AllGather(recs + world, recs, 4, kNcclInt64, c->comm, h->stream));
+      MT_HIP(h, hipMemcpyAsync(host.data() + kReduceBlocks, recs, sizeof(ReducePartial) * (size_t)world,
+                               hipMemcpyDeviceToHost, h->stream));
+      MT_HIP(h, hipStreamSynchronize(h->stream));
+      all = ReducePartial{0.0, 1.0e300, -1.0e300, 0.0};
+      for (int k = 0; k < world; ++k) {  // rank order: the same result on every rank
+        const ReducePartial& p = host[(size_t)kReduceBlocks + (size_t)k];
+        all.sum += p.sum;
+        all.min = p.min < all.min ? p.min : all.min;
+        all.max = p.max > all.max ? p.max : all.max;
+        all.done += p.done;
+      }
+      count = c->total;
+    }
+    out->sum = all.sum;
+    out->min = all.min;
+    out->max = all.max;
+    out->count = count;
+    out->done = (int64_t)all.done;
+    return MT_OK;
+  };
+  rc = body();
+  (void)hipFree(d);
+  return rc;
 }
 
 int mt_gather_returns_begin(mt_handle h, int field, int row, float* dst, int64_t dst_elems) {

@@ -479,6 +479,15 @@ class StepEngine:
         self._call(self._lib.mt_comm_total_envs, C.byref(t))
         return int(t.value)
 
+    def return_stats(self, field=None, row=0) -> dict:
+        """{sum, min, max, mean, count, done} of a return row over ALL ranks (mt_reduce_returns): reduced on the device,
+        five numbers per rank exchanged -- what a learner logs per episode without moving the row.  Synchronous;
+        collective when a communicator is attached."""
+        st = L.MtReturnStats()
+        self._call(self._lib.mt_reduce_returns, int(L.F_TOTAL_REWARD if field is None else field), int(row), C.byref(st))
+        return {"sum": st.sum, "min": st.min, "max": st.max, "mean": st.sum / max(1, st.count), "count": int(st.count),
+                "done": int(st.done)}
+
     def _gather_out(self, out):
         import torch
         n_total = self.total_envs()

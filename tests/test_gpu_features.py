@@ -226,6 +226,11 @@ def test_gather_returns_without_and_with_a_one_rank_rccl_communicator(m):
     np.testing.assert_array_equal(out.cpu().numpy(), eng.last_return())
     with pytest.raises(ValueError):
         eng.gather_returns(torch.zeros(n - 1, dtype=torch.float32, device="cuda"))
+    # mt_reduce_returns: the summary a learner logs, through the one-rank communicator and (below) without one
+    st = eng.return_stats()
+    assert st["count"] == n and st["sum"] == float(ref.astype(np.float64).sum())
+    assert st["min"] == float(ref.min()) and st["max"] == float(ref.max()) and st["done"] == int(eng.done().sum())
+    assert eng.return_stats(field=m.lib.F_LAST_RETURN)["sum"] == float(eng.last_return().astype(np.float64).sum())
     # overlapped form, through the communicator: snapshot on the engine's stream, exchange on its side stream; the
     # reset and the steps queued right behind it must not leak into the result
     for rep in range(3):
@@ -244,6 +249,7 @@ def test_gather_returns_without_and_with_a_one_rank_rccl_communicator(m):
     np.testing.assert_array_equal(out4.cpu().numpy(), want)
     eng.comm_destroy()
     # without a communicator the overlapped form is a device copy on the side stream
+    assert eng.return_stats() == st | {"sum": 0.0, "min": 0.0, "max": 0.0, "mean": 0.0, "done": 0}    # after reset_random(2, 9)
     out5 = eng.gather_begin()
     eng.rollout(3, 2, 0)
     eng.gather_wait(host=True)

@@ -48,6 +48,7 @@ def _worker(rank, world, port, n_total, lib, q):
     assert eng.total_envs() == n_total
     in_line = eng.gather_returns()
     eng.sync()
+    stats = eng.return_stats()                           # mt_reduce_returns: five numbers per rank over the communicator
     overlapped = eng.gather_begin()                      # snapshot + exchange on the side stream ...
     eng.reset_random(5, 1)                               # ... while the returns are zeroed and the next steps run
     eng.rollout(3, 5, 0)
@@ -55,8 +56,12 @@ def _worker(rank, world, port, n_total, lib, q):
     assert ms is not None
     second = eng.gather_returns(field=m.lib.F_TOTAL_REWARD)    # the returns of the 3 steps after the reset
     eng.sync()
+    stats2 = eng.return_stats()                          # right behind an overlapped gather on the same communicator
+    every = [None] * world
+    dist.all_gather_object(every, (stats, stats2))
+    assert all(s == every[0] for s in every)             # the same numbers on every rank
     if rank == 0:
-        q.put((in_line.cpu().numpy(), overlapped.cpu().numpy(), second.cpu().numpy()))
+        q.put((in_line.cpu().numpy(), overlapped.cpu().numpy(), second.cpu().numpy(), stats, stats2))
     dist.barrier()
     eng.comm_destroy()
     eng.close()
@@ -75,7 +80,7 @@ def test_multi_rank_gather_through_the_c_abi_with_a_stand_in_transport(world, n_
     procs = [ctx.Process(target=_worker, args=(r, world, port, n_total, lib, q)) for r in range(world)]
     for p in procs:
         p.start()
-    in_line, overlapped, second = q.get(timeout=240)
+    in_line, overlapped, second, stats, stats2 = q.get(timeout=240)
     for p in procs:
         p.join(timeout=240)
         assert p.exitcode == 0
@@ -89,3 +94,7 @@ def test_multi_rank_gather_through_the_c_abi_with_a_stand_in_transport(world, n_
     whole.rollout(3, 5, 0)
     np.testing.assert_array_equal(second, whole.total_reward())
     assert np.abs(want).max() > 0
+    for got, ret in ((stats, want), (stats2, whole.total_reward())):
+        assert got["count"] == n_total and got["sum"] == float(ret.astype(np.float64).sum())
+        assert got["min"] == float(ret.min()) and got["max"] == float(ret.max())
+    assert stats2 == whole.return_stats()                # one handle owning every env gives the same five numbers

@@ -88,6 +88,10 @@ int main(void) {
   rc[1] = mt_comm_total_envs(0, &total);
   rc[2] = mt_bad_action_count(0, &bad);
   rc[3] = mt_env_step(0, 0, 0, 0, 0, 0);
+  {
+    mt_return_stats st;
+    if (mt_reduce_returns(0, MT_F_TOTAL_REWARD, 0, &st) != MT_ERR_INVALID_ARG || sizeof st != 40) return 2;
+  }
   printf("%d|%s|%d|%s|%d|%d|%d|%d\n", mt_version(), mt_status_string(MT_ERR_STATE), rc_create, msg, rc[0], rc[1], rc[2], rc[3]);
   return h != 0;
 }
