@@ -364,12 +364,14 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available() or m.device_count() < 1:
         raise SystemExit("bench.py needs a GPU: the step path has no CPU fallback")
-    dev = 0 if (args.rehearsal or args.single_device) else local_rank
+    # one process per GPU: LOCAL_RANK names the device, unless the launcher already narrowed every process's view to
+    # its own card (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES per rank), in which case there is only device 0
+    dev = 0 if (args.rehearsal or args.single_device) else local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev)
     backend = "gloo" if args.rehearsal else args.backend
     if world > 1:
         if backend == "nccl":
-            D.init_process_group("nccl")
+            D.init_process_group("nccl", device=dev)
         else:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             dist.init_process_group(backend="gloo", rank=rank, world_size=world)

@@ -32,7 +32,7 @@ def main():
 
     rank, local_rank, world = D.init_process_group()                   # no-op for a single process
     base, n_local = D.shard_range(opt.envs_total, rank, world)         # contiguous global env ids of this rank
-    eng = m.StepEngine(n_local, opt.targets, device=local_rank, env_id_base=base)
+    eng = m.StepEngine(n_local, opt.targets, device=local_rank % m.device_count(), env_id_base=base)
     if world > 1:
         D.connect(eng, rank, world)                                    # RCCL communicator of the engine (C ABI)
     eng.reset_random(opt.seed, 0)

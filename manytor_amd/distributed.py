@@ -38,8 +38,9 @@ def env_from_torchrun():
             int(os.environ.get("WORLD_SIZE", "1")))
 
 
-def init_process_group(backend=None):
-    """Initialise torch.distributed from the torchrun environment (no-op for a single process)."""
+def init_process_group(backend=None, device=None):
+    """Initialise torch.distributed from the torchrun environment (no-op for a single process).  `device`: the GPU of
+    this rank (default LOCAL_RANK, modulo the number of visible devices in case the launcher shows each rank one card)."""
     import torch
     import torch.distributed as dist
     rank, local_rank, world = env_from_torchrun()
@@ -48,9 +49,11 @@ def init_process_group(backend=None):
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
-            torch.cuda.set_device(local_rank)
+            if device is None:
+                device = local_rank % max(1, torch.cuda.device_count())
+            torch.cuda.set_device(device)
             dist.init_process_group(backend=backend, rank=rank, world_size=world,
-                                    device_id=torch.device("cuda", local_rank))
+                                    device_id=torch.device("cuda", device))
         else:
             dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local_rank, world
