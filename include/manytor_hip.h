@@ -191,7 +191,8 @@ MT_API int mt_bad_action_count(mt_handle h, uint64_t* count);
  * step, manytor.py:184), which saves 4*D bytes of traffic per env. */
 MT_API int mt_step_random(mt_handle h, uint64_t seed, uint32_t step_idx);
 /* n_steps x mt_step_random with step indices step_idx0, step_idx0+1, ... (the
- * inner loop of test_multi.py:19-21). */
+ * inner loop of test_multi.py:19-21).  On small batches (<= 131 072 envs) the launches are replayed from a HIP graph
+ * that the handle captures once per segment length: the same kernels, the same results, less time per kernel boundary. */
 MT_API int mt_rollout(mt_handle h, int n_steps, uint64_t seed, uint32_t step_idx0);
 /* The same n_steps steps in ONE launch: joint angles, alive mask and return stay in registers and the targets
  * in LDS between steps, so a step only writes its outputs (obs, reward, done, end effector; MT_F_* hold the last

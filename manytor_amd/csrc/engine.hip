@@ -405,6 +405,7 @@ int mt_create(mt_handle* out, const mt_config* cfg) {
   // 131 072, slower above (same bits; MT_RESET_SPLIT = 0/1 overrides).
   h->reset_split = cfg->n_envs <= 65536;
   if (const char* env = std::getenv("MT_RESET_SPLIT")) h->reset_split = std::atoi(env) != 0;
+  if (const char* env = std::getenv("MT_GRAPH")) h->graph_mode = std::atoi(env) != 0 ? 1 : 0;
   h->prefetch_forced = false;
   if (const char* env = std::getenv("MT_PREFETCH")) {
     h->prefetch = std::atoi(env) != 0;
@@ -503,6 +504,8 @@ int mt_destroy(mt_handle h) {
   (void)hipStreamSynchronize(h->stream);
   mt_gather_release(h);  // drains the side stream before the communicator goes
   mt_comm_release(h);
+  for (auto& g : h->graphs) (void)hipGraphExecDestroy(g.exec);
+  if (h->graph_step0) (void)hipFree(h->graph_step0);
   if (h->staging) (void)hipFree(h->staging);
   if (h->pinned) (void)hipHostFree(h->pinned);
   if (h->arena) (void)hipFree(h->arena);
@@ -794,9 +797,82 @@ int mt_bad_action_count(mt_handle h, uint64_t* count) {
   return MT_OK;
 }
 
+// mt_rollout on small batches is bound by the kernel boundary, not by the kernels (profiles/r02_variants.md section 3):
+// the T launches of a segment are captured once into a HIP graph (stream capture of the very same launches; each node's
+// step index = its offset + a device word) and replayed -- 5-15 % less per step up to 131 072 arms, nothing above.
+static bool rollout_uses_graph(mt_handle h, int n_steps) {
+  if (h->graph_mode == 0 || h->trace || n_steps < 4) return false;
+  if (h->graph_mode < 0 && h->n > 131072) return false;
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(h->stream, &st) != hipSuccess || st != hipStreamCaptureStatusNone) {
+    (void)hipGetLastError();
+    return false;  // the caller is capturing this stream into a graph of their own: plain launches
+  }
+  return true;
+}
+
+static int rollout_graph(mt_handle h, int T, uint64_t seed, hipGraphExec_t* out) {
+  if (!h->graph_step0) MT_HIP(h, hipMalloc(&h->graph_step0, sizeof(uint32_t)));
+  StepArgs a = h->args;
+  a.seed_lo = (uint32_t)seed;
+  a.seed_hi = (uint32_t)(seed >> 32);
+  a.major = 0;
+  a.episode0 = 0;  // not read by the step kernels
+  a.major_base = h->graph_step0;
+  for (auto& g : h->graphs)
+    if (g.T == T && std::memcmp(&g.args, &a, sizeof a) == 0) {
+      *out = g.exec;
+      return MT_OK;
+    }
+  // captured on the handle's private stream whatever stream the handle currently launches on (the caller's may be the
+  // null stream, which cannot capture); the instantiated graph is launched on the current one
+  hipGraph_t graph = nullptr;
+  hipStream_t launch_stream = h->stream;
+  MT_HIP(h, hipStreamBeginCapture(h->own_stream, hipStreamCaptureModeThreadLocal));
+  h->stream = h->own_stream;
+  for (int s = 0; s < T; ++s) {
+    StepArgs as = a;
+    as.major = (uint32_t)s;
+    launch_step(h, as, nullptr, true);
+  }
+  h->stream = launch_stream;
+  hipError_t e = hipStreamEndCapture(h->own_stream, &graph);
+  if (e != hipSuccess || !graph) {
+    (void)hipGetLastError();
+    return fail(h, MT_ERR_HIP, std::string("mt_rollout: stream capture failed: ") + hipGetErrorString(e));
+  }
+  hipGraphExec_t exec = nullptr;
+  e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(graph);
+  if (e != hipSuccess) return fail(h, MT_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
+  if (h->graphs.size() >= 8) {  // a handful of segment lengths at most; drop the oldest beyond that
+    MT_HIP(h, hipStreamSynchronize(h->stream));
+    (void)hipGraphExecDestroy(h->graphs.front().exec);
+    h->graphs.erase(h->graphs.begin());
+  }
+  h->graphs.push_back(mt_engine::RolloutGraph{T, a, exec});
+  *out = exec;
+  return MT_OK;
+}
+
 int mt_rollout(mt_handle h, int n_steps, uint64_t seed, uint32_t step_idx0) {
   MT_REQUIRE(nullptr, h != nullptr, "handle is NULL");
   MT_REQUIRE(h, n_steps >= 0, "n_steps must be >= 0");
+  if (n_steps > 0 && !h->is_reset) return fail(h, MT_ERR_STATE, "mt_rollout before mt_reset / mt_reset_random");
+  if (n_steps > 0) {
+    MT_ON_DEVICE(h, h->cfg.device);
+    if (rollout_uses_graph(h, n_steps)) {
+      hipGraphExec_t exec = nullptr;
+      int rc = rollout_graph(h, n_steps, seed, &exec);
+      if (rc) return rc;
+      MT_HIP(h, hipMemsetD32Async((hipDeviceptr_t)h->graph_step0, (int)step_idx0, 1, h->stream));
+      MT_HIP(h, hipGraphLaunch(exec, h->stream));
+      h->args.seed_lo = (uint32_t)seed;
+      h->args.seed_hi = (uint32_t)(seed >> 32);
+      h->args.major = step_idx0 + (uint32_t)(n_steps - 1);
+      return MT_OK;
+    }
+  }
   for (int s = 0; s < n_steps; ++s) {
     int rc = mt_step_random(h, seed, step_idx0 + (uint32_t)s);
     if (rc) return rc;

@@ -43,6 +43,15 @@ struct mt_engine {
   hipEvent_t ev_snap = nullptr, ev_g0 = nullptr, ev_g1 = nullptr;
   float* snap = nullptr;
   bool reset_split = false;  // mt_reset_random / mt_reset_done of the whole batch: reset_split_kernel
+  // mt_rollout on small batches: the segment's launches are captured once into a HIP graph and replayed
+  struct RolloutGraph {
+    int T;
+    mt::StepArgs args;  // what the nodes were captured with (major = 0, episode0 = 0): any change rebuilds the graph
+    hipGraphExec_t exec;
+  };
+  std::vector<RolloutGraph> graphs;
+  uint32_t* graph_step0 = nullptr;  // device word: first step index of the segment being replayed
+  int graph_mode = -1;              // -1 by batch size, 0 never, 1 always (MT_GRAPH)
   bool gather_pending = false;
   float last_gather_ms = 0.f;  // device time of the last exchange that was waited for (mt_gather_returns_wait / mt_sync)
   std::string err;

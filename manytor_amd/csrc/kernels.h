@@ -285,6 +285,11 @@ struct TableMaker<RtTableF<D>> {
   static __device__ __forceinline__ RtTableF<D> make(const DhConst& c) { return RtTableF<D>{c}; }
 };
 
+// The step index that keys this launch's action draw (see StepArgs::major_base; the address is wave-uniform: s_load).
+__device__ __forceinline__ uint32_t step_index(const StepArgs& a) {
+  return a.major_base ? a.major + *a.major_base : a.major;
+}
+
 // Environment.action_sample for one env (manytor.py:215-217): D integer degrees from one Philox block.
 template <int D>
 __device__ __forceinline__ void draw_action(uint64_t seed, uint64_t env_id, uint32_t step_idx, float (&act)[D]) {
@@ -671,7 +676,7 @@ __global__ __launch_bounds__(kBlock, (PF ? 1 : step_min_waves<Tbl, TRIG>())) voi
   }
   if (SAMPLE) {
     // not stored separately: the action taken becomes `goals` below (manytor.py:184), 4D bytes of traffic saved
-    draw_action<D>(((uint64_t)a.seed_hi << 32) | a.seed_lo, (uint64_t)(a.env_base + i), a.major, act);
+    draw_action<D>(((uint64_t)a.seed_hi << 32) | a.seed_lo, (uint64_t)(a.env_base + i), step_index(a), act);
   } else {
     bool bad = false;
 #pragma unroll
@@ -871,7 +876,7 @@ __global__ __launch_bounds__(kBlock) void step_split_kernel(const StepArgs a) {
   const uint32_t am = a.alive[i];
   const float total_in = a.total_reward[i];
   if (SAMPLE) {
-    draw_action<D>(((uint64_t)a.seed_hi << 32) | a.seed_lo, (uint64_t)(a.env_base + i), a.major, act);
+    draw_action<D>(((uint64_t)a.seed_hi << 32) | a.seed_lo, (uint64_t)(a.env_base + i), step_index(a), act);
   } else {
     bool bad = false;
 #pragma unroll
@@ -969,7 +974,7 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(const StepArgs a, float* 
 #pragma unroll
   for (int j = 0; j < D; ++j) g[j] = ldr(a.goals + j * ld, i * 4u);
   if (SAMPLE) {
-    draw_action<D>(((uint64_t)a.seed_hi << 32) | a.seed_lo, (uint64_t)(a.env_base + i), a.major, act);
+    draw_action<D>(((uint64_t)a.seed_hi << 32) | a.seed_lo, (uint64_t)(a.env_base + i), step_index(a), act);
   } else {
     bool bad = false;
 #pragma unroll

@@ -42,6 +42,9 @@ struct StepArgs {
   float tol, inv_sm1;
   uint32_t flags;
   uint32_t seed_lo, seed_hi, major;  // RNG key + step / episode index
+  // Launches replayed from a HIP graph (mt_rollout on small batches): `major` is the launch's offset inside the
+  // segment and the segment's first step index sits in this device word, which the host sets before every replay.
+  const uint32_t* major_base;
   DhConst dh;
 #ifdef MT_STAMPS
   unsigned long long* stamps;  // diagnostic build only (tools/microbench/step_stamps.hip): [waves][8] shader-clock stamps

@@ -1001,6 +1001,47 @@ def test_rccl_single_rank_gather_of_engine_memory(m):
     eng.comm_destroy()
 
 
+@pytest.mark.parametrize("case", ["ref_small", "ref_split", "dh7", "runtime5", "ref_large_forced"])
+def test_rollout_through_a_replayed_graph_equals_plain_launches(m, case, monkeypatch):
+    """mt_rollout replays a captured HIP graph of its T launches on small batches (MT_GRAPH forces it on / off): the
+    same bits as T plain launches, across segment lengths, step offsets, seeds, resets, a stream change and the
+    eviction of cached graphs."""
+    kw, n, k = {"ref_small": (dict(), 100003, 7), "ref_split": (dict(), 20000, 3),
+                "dh7": (dict(dh_table=m.DH7_TABLE, radius=92.6), 3001, 7),
+                "runtime5": (dict(dh_table=[[0, -1.2, 5, 0], [6, 0.37, 0, 0.2], [0, 1.57, 7, 0], [4, 0, 0, 0], [3, -1.57, 2, 0]],
+                                  radius=25.0), 7777, 5),
+                "ref_large_forced": (dict(), 300000, 7)}[case]
+    fields = ("F_GOALS", "F_ALIVE", "F_TOTAL_REWARD", "F_POINTS", "F_OBS", "F_REWARD", "F_DONE", "F_DONE_BITS", "F_EE")
+    outs = []
+    for mode in ("0", "1"):
+        monkeypatch.setenv("MT_GRAPH", mode)
+        eng = m.StepEngine(n, k, pickup_tol=15.0, **kw)
+        eng.reset_random(8, 0)
+        step = 0
+        snaps = []
+        for rep, T in enumerate((50, 20, 50, 7, 4, 3, 50)):           # 3 < 4: plain launches in both modes
+            seed = 8 if rep < 5 else 99                               # a new seed makes new graphs
+            eng.rollout(T, seed, step)
+            step += T
+            if rep == 2:
+                eng.reset_random(8, 1)
+            if rep == 3:
+                eng.step_random(8, 1234)                              # a plain launch between two replays
+            snaps.append({f: eng.get(getattr(m.lib, f)) for f in fields})
+        for T in range(10, 20):                                       # more segment lengths than the cache holds
+            eng.rollout(T, 8, 5000 + T)
+        eng.use_torch_stream()                                        # the graphs are not tied to the stream they were captured on
+        eng.rollout(50, 8, 7000)
+        eng.set_stream(None)
+        eng.rollout(50, 8, 8000)
+        snaps.append({f: eng.get(getattr(m.lib, f)) for f in fields})
+        outs.append(snaps)
+        eng.close()
+    for a, b in zip(*outs):
+        for f in fields:
+            np.testing.assert_array_equal(a[f], b[f], err_msg=f)
+
+
 def test_step_is_capturable_in_a_hip_graph(m):
     """mt_step launches on the caller's stream and does nothing capture-hostile (no allocation, no sync), so a
     torch stream capture records `write actions -> env step` as one HIP graph; replays equal eager stepping."""
