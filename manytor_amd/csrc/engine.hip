@@ -861,7 +861,19 @@ int mt_rollout(mt_handle h, int n_steps, uint64_t seed, uint32_t step_idx0) {
   if (n_steps > 0 && !h->is_reset) return fail(h, MT_ERR_STATE, "mt_rollout before mt_reset / mt_reset_random");
   if (n_steps > 0) {
     MT_ON_DEVICE(h, h->cfg.device);
-    if (rollout_uses_graph(h, n_steps)) {
+    bool graph = rollout_uses_graph(h, n_steps);
+    if (graph && h->graph_mode < 0) {
+      // capture + instantiation cost about a dozen plain segments: only for a segment length that comes back
+      bool cached = false, seen = false;
+      for (auto& g : h->graphs) cached |= g.T == n_steps;
+      for (int t : h->graph_seen) seen |= t == n_steps;
+      if (!cached && !seen) {
+        if (h->graph_seen.size() >= 32) h->graph_seen.erase(h->graph_seen.begin());
+        h->graph_seen.push_back(n_steps);
+        graph = false;
+      }
+    }
+    if (graph) {
       hipGraphExec_t exec = nullptr;
       int rc = rollout_graph(h, n_steps, seed, &exec);
       if (rc) return rc;

@@ -50,6 +50,7 @@ struct mt_engine {
     hipGraphExec_t exec;
   };
   std::vector<RolloutGraph> graphs;
+  std::vector<int> graph_seen;      // segment lengths asked for once: a graph is built at the second request
   uint32_t* graph_step0 = nullptr;  // device word: first step index of the segment being replayed
   int graph_mode = -1;              // -1 by batch size, 0 never, 1 always (MT_GRAPH)
   bool gather_pending = false;
