@@ -40,7 +40,7 @@ extern "C" {
 #define MT_API
 #endif
 
-#define MT_VERSION 200          /* major*10000 + minor*100 + patch */
+#define MT_VERSION 300          /* major*10000 + minor*100 + patch */
 #define MT_MAX_DOF 8
 #define MT_MAX_TARGETS 32
 #define MT_MAX_RETURN_RING 64
@@ -79,7 +79,10 @@ typedef enum mt_field {
                           /*             c % R; c = MT_F_EPISODES - (episode of the last full reset)                     */
   MT_F_TRACE = 14,        /* f32  (N, S, 3) rows: 3S.  End effector at each of the S sub-step poses of the last step     */
                           /*             (the rows manytor.py:190 appends to `trajectory`); needs MT_FLAG_TRACE          */
-  MT_F_COUNT = 15
+  MT_F_ZMIN = 15,         /* f32  (N,)   DEBUG (needs MT_FLAG_DEBUG_ZMIN): signed minimum z of the observation and pickup     */
+                          /*             frames over ALL S sub-step poses of the last step, exactly the value the step     */
+                          /*             kernel compares with 0 for the ground flag (manytor.py:191-192)                    */
+  MT_F_COUNT = 16
 } mt_field;
 
 typedef enum mt_dtype { MT_F32 = 0, MT_F64 = 1, MT_I32 = 2, MT_I64 = 3, MT_U8 = 4, MT_U32 = 5, MT_U64 = 6 } mt_dtype;
@@ -95,6 +98,9 @@ typedef enum mt_layout { MT_ENV_MAJOR = 0, MT_SOA = 1 } mt_layout;
 #define MT_FLAG_NO_SPECIALIZE 0x10u      /* never use a compile-time DH table, even if the table matches one       */
 #define MT_FLAG_TRACE 0x20u              /* keep MT_F_TRACE: every step also writes the end effector of each       */
                                          /* sub-step pose (300 B/env-step at S = 25; off by default, manytor.py:190) */
+#define MT_FLAG_DEBUG_ZMIN 0x40u         /* keep MT_F_ZMIN: the step / rollout kernels also store the z-minimum    */
+                                         /* their ground test used (4 B/env-step; parity tests pin the sub-step    */
+                                         /* recurrence of the timed kernels with it; off by default)               */
 /* Profiling builds.  OUTPUTS ARE WRONG ON PURPOSE; never set outside bench.py --ablate. */
 #define MT_FLAG_ABLATE_LOOP 0x100u       /* skip the interior sub-steps                                            */
 #define MT_FLAG_ABLATE_OBS 0x200u        /* with ABLATE_LOOP: also skip the observation arithmetic (memory only);  */
@@ -212,8 +218,14 @@ MT_API int mt_check_done(mt_handle h);
  * (is_device = 0, synchronises) or device memory.  dst_bytes must match. */
 MT_API int mt_get(mt_handle h, int field, void* dst, int64_t dst_bytes, int is_device);
 /* Overwrite GOALS / POINTS / ALIVE(u8 N,K) / TOTAL_REWARD from host env-major
- * arrays (attribute assignment on the reference objects, e.g. manytor.py:243). */
+ * arrays (attribute assignment on the reference objects, e.g. manytor.py:243), and -- for restoring a checkpoint --
+ * DONE (u8 N; the ballot words are rebuilt), EPISODES (u32 N), LAST_RETURN (f32 N), RETURN_RING (f32 N,R).
+ * Floating-point input is screened: NaN / +-inf anywhere, or a joint angle beyond +-32768 degrees, is
+ * MT_ERR_INVALID_ARG and nothing is written (the kernels assume finite state). */
 MT_API int mt_set(mt_handle h, int field, const void* src, int64_t src_bytes);
+/* The episode index every env was given by the last full reset (finished-episode counts and return-ring slots are
+ * relative to it): mt_reset / mt_reset_random set it; a checkpoint restore sets it back with this call. */
+MT_API int mt_set_episode_base(mt_handle h, uint32_t episode0);
 /* Raw resident buffer: pointer to row 0, number of rows, row stride in elements and element dtype. */
 MT_API int mt_device_ptr(mt_handle h, int field, void** ptr, int64_t* rows, int64_t* ld, int* dtype);
 

@@ -28,7 +28,7 @@ MT_ERR_UNSUPPORTED = -6
 
 # mt_field
 (F_ACTIONS, F_GOALS, F_POINTS, F_ALIVE, F_OBS, F_REWARD, F_DONE, F_DONE_BITS, F_EE, F_TOTAL_REWARD, F_JOINTS,
- F_EPISODES, F_LAST_RETURN, F_RETURN_RING, F_TRACE) = range(15)
+ F_EPISODES, F_LAST_RETURN, F_RETURN_RING, F_TRACE, F_ZMIN) = range(16)
 # mt_dtype
 DT_F32, DT_F64, DT_I32, DT_I64, DT_U8, DT_U32, DT_U64 = range(7)
 # mt_layout
@@ -40,6 +40,7 @@ FLAG_DH_IN_LDS = 0x4
 FLAG_DIRECT_TRIG = 0x8
 FLAG_NO_SPECIALIZE = 0x10
 FLAG_TRACE = 0x20
+FLAG_DEBUG_ZMIN = 0x40
 FLAG_ABLATE_LOOP = 0x100
 FLAG_ABLATE_OBS = 0x200
 
@@ -107,6 +108,7 @@ PROTOTYPES = {
     "mt_check_done": (C.c_int, [_HANDLE]),
     "mt_get": (C.c_int, [_HANDLE, C.c_int, C.c_void_p, C.c_int64, C.c_int]),
     "mt_set": (C.c_int, [_HANDLE, C.c_int, C.c_void_p, C.c_int64]),
+    "mt_set_episode_base": (C.c_int, [_HANDLE, C.c_uint32]),
     "mt_device_ptr": (C.c_int, [_HANDLE, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_int64),
                                 C.POINTER(C.c_int)]),
     "mt_comm_unique_id": (C.c_int, [C.c_void_p]),

@@ -148,7 +148,13 @@ class _EnvView:
         if o.rng == "numpy":
             o._engine.env_reset(self.id, _rng.draw_targets(1, o.obj_number, o.radius)[0])
         else:
-            o._engine.env_reset(self.id, None, seed=o.seed, episode=o._episode)
+            # fresh targets at every call (manytor.py:229 draws anew each time) WITHOUT touching the env's episode
+            # counter: the draw is keyed by a per-env count of single-env resets folded into the seed, and the env keeps
+            # the episode index it has, so finished() / the next whole-batch reset are unaffected
+            cnt = o._env_resets.get(self.id, 0) + 1
+            o._env_resets[self.id] = cnt
+            seed = (o.seed ^ (cnt * 0x9E3779B97F4A7C15)) & 0xFFFFFFFFFFFFFFFF
+            o._engine.env_reset(self.id, None, seed=seed, episode=int(o._cached(L.F_EPISODES)[self.id]))
         if returnable:
             return self.get_observations()
 
@@ -201,6 +207,7 @@ class Multienv:
                                   terminate_on_ground=terminate_on_ground, **engine_kwargs)
         self._materialize = (self.env_number <= _MATERIALIZE_LIMIT) if materialize == "auto" else bool(materialize)
         self._cache = {}
+        self._env_resets = {}          # env index -> number of environment[i].reset() calls (device RNG mode)
         self.environment = _EnvList(self)
 
     @property
@@ -379,6 +386,13 @@ class Environment:
         self._engine.check_done()
         return bool(self._engine.done()[0])
 
+    @staticmethod
+    def _usable(act) -> bool:
+        """The kernel's own test (kernels.h: unusable_angle): an action with a NaN / inf / |angle| > 32768 component is
+        rejected and the env holds its pose for that step."""
+        a = np.asarray(act, dtype=np.float32)
+        return bool(np.all(np.isfinite(a)) and np.all(np.abs(a) <= 32768.0))
+
     def _after_route(self, prev, action):
         """Host-side bookkeeping the reference does per sub-step (manytor.py:190, :194-202): the trajectory rows (noted
         here, computed when read) and, while rendering, the viewer frames of the route just taken."""
@@ -398,6 +412,8 @@ class Environment:
         act = np.asarray(action, dtype=np.float64).reshape(1, -1)
         self._engine.step(act)
         self._engine.set(L.F_TOTAL_REWARD, before)
+        if not self._usable(act):                         # rejected by the kernel: the pose was held
+            act = prev.astype(np.float64)
         self._pose = act.astype(np.float32)               # goals = action after a step (manytor.py:184)
         self._after_route(prev, act)
         return int(self._engine.reward()[0]), self._engine.obs()[0].astype(np.float64)
@@ -429,6 +445,8 @@ class Environment:
         act = np.asarray(action, dtype=np.float64).reshape(1, -1)
         obs, rew, done = self._engine.step_host(act)
         self._step_idx += 1
+        if not self._usable(act):                         # rejected by the kernel: the pose was held
+            act = prev.astype(np.float64)
         self._pose = act.astype(np.float32)               # goals = action after a step (manytor.py:184)
         self._after_route(prev, act)
         return obs[0].astype(np.float64), int(rew[0]), bool(done[0])

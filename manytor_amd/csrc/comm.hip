@@ -111,6 +111,9 @@ void mt_gather_release(mt_handle h) {
   if (h->ev_g0) (void)hipEventDestroy(h->ev_g0);
   if (h->ev_g1) (void)hipEventDestroy(h->ev_g1);
   if (h->snap) (void)hipFree(h->snap);
+  if (h->reduce_scratch) (void)hipFree(h->reduce_scratch);
+  h->reduce_scratch = nullptr;
+  h->reduce_scratch_bytes = 0;
   h->side_stream = nullptr;
   h->ev_snap = h->ev_g0 = h->ev_g1 = nullptr;
   h->snap = nullptr;
@@ -341,8 +344,20 @@ int mt_reduce_returns(mt_handle h, int field, int row, mt_return_stats* out) {
   const int world = (c && c->world > 1) ? c->world : 1;
   // device scratch: [kReduceBlocks] block partials, then [world + 1] per-rank records (slot `world` = this rank's)
   const size_t bytes = sizeof(ReducePartial) * (size_t)(kReduceBlocks + world + 1);
-  ReducePartial* d = nullptr;
-  MT_HIP(h, hipMalloc(&d, bytes));
+  if (h->reduce_scratch_bytes < bytes) {  // kept on the handle: no hipMalloc / hipFree (= device-wide sync) per call
+    if (h->reduce_scratch) {
+      MT_HIP(h, hipStreamSynchronize(h->stream));
+      (void)hipFree(h->reduce_scratch);
+      h->reduce_scratch = nullptr;
+      h->reduce_scratch_bytes = 0;
+    }
+    if (hipMalloc(&h->reduce_scratch, bytes) != hipSuccess) {
+      (void)hipGetLastError();
+      return fail(h, MT_ERR_ALLOC, "hipMalloc of the reduce scratch failed");
+    }
+    h->reduce_scratch_bytes = bytes;
+  }
+  ReducePartial* d = (ReducePartial*)h->reduce_scratch;
   std::vector<ReducePartial> host((size_t)kReduceBlocks + (size_t)world);
   auto body = [&]() -> int {
     hipLaunchKernelGGL(reduce_returns_kernel, dim3(kReduceBlocks), dim3(kBlock), 0, h->stream, src, h->args.done, h->n, d);
@@ -388,9 +403,7 @@ int mt_reduce_returns(mt_handle h, int field, int row, mt_return_stats* out) {
     out->done = (int64_t)all.done;
     return MT_OK;
   };
-  rc = body();
-  (void)hipFree(d);
-  return rc;
+  return body();
 }
 
 int mt_gather_returns_begin(mt_handle h, int field, int row, float* dst, int64_t dst_elems) {
@@ -400,14 +413,17 @@ int mt_gather_returns_begin(mt_handle h, int field, int row, float* dst, int64_t
   const float* src = gather_source(h, field, row, &rc);
   if (!src) return rc;
   MT_ON_DEVICE(h, h->cfg.device);
-  if (!h->side_stream) {  // first use: the side stream, its events, and the snapshot row
-    MT_HIP(h, hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
-    MT_HIP(h, hipEventCreateWithFlags(&h->ev_snap, hipEventDisableTiming));
-    MT_HIP(h, hipEventCreate(&h->ev_g0));
-    MT_HIP(h, hipEventCreate(&h->ev_g1));
-    if (hipMalloc(&h->snap, sizeof(float) * (size_t)h->n) != hipSuccess) {
+  if (!h->snap) {  // first use: the side stream, its events, and the snapshot row (`snap` is set last: all or nothing)
+    hipError_t e = hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_snap, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreate(&h->ev_g0);
+    if (e == hipSuccess) e = hipEventCreate(&h->ev_g1);
+    if (e == hipSuccess) e = hipMalloc(&h->snap, sizeof(float) * (size_t)h->n);
+    if (e != hipSuccess) {
       (void)hipGetLastError();
-      return fail(h, MT_ERR_ALLOC, "hipMalloc of the return snapshot failed");
+      mt_gather_release(h);  // whatever was created goes again: the next call starts from scratch
+      return fail(h, e == hipErrorOutOfMemory ? MT_ERR_ALLOC : MT_ERR_HIP,
+                  std::string("mt_gather_returns_begin: set-up of the side stream failed: ") + hipGetErrorString(e));
     }
   }
   // the snapshot may only be overwritten once the previous exchange has read it

@@ -163,6 +163,13 @@ void launch_trace_d(mt_handle h, const StepArgs& args, float* trace, bool sample
 template <int D>
 void launch_step_frames_d(mt_handle h, const StepArgs& args, bool sample) {
   const dim3 g = grid_for(args.n), b(kBlock);
+  if (h->trig == 1) {  // long routes (mt_create: more than 12 rotations per half) or MT_FLAG_DIRECT_TRIG
+    if (sample)
+      hipLaunchKernelGGL((step_kernel<RtTableF<D>, true, 1, false, 0>), g, b, 0, h->stream, args);
+    else
+      hipLaunchKernelGGL((step_kernel<RtTableF<D>, false, 1, false, 0>), g, b, 0, h->stream, args);
+    return;
+  }
   if (sample)
     hipLaunchKernelGGL((step_kernel<RtTableF<D>, true, 0, false, 0>), g, b, 0, h->stream, args);
   else
@@ -201,6 +208,7 @@ StepArgs args_for_env(mt_handle h, int64_t env) {
   a.episodes += env;
   a.last_return += env;
   if (a.ring) a.ring += env;
+  if (a.zmin) a.zmin += env;
   a.n = 1;
   a.env_base += env;
   return a;
@@ -307,6 +315,10 @@ int field_info(mt_handle h, int field, FieldInfo* fi) {
       if (!h->trace) return fail(h, MT_ERR_STATE, "MT_F_TRACE: the handle was created without MT_FLAG_TRACE");
       *fi = {h->trace, 3 * h->cfg.substeps, MT_F32, 4};
       return MT_OK;
+    case MT_F_ZMIN:
+      if (!a.zmin) return fail(h, MT_ERR_STATE, "MT_F_ZMIN: the handle was created without MT_FLAG_DEBUG_ZMIN");
+      *fi = {a.zmin, 1, MT_F32, 4};
+      return MT_OK;
     default: return fail(h, MT_ERR_INVALID_ARG, "unknown or non-resident field");
   }
 }
@@ -314,6 +326,19 @@ int field_info(mt_handle h, int field, FieldInfo* fi) {
 }  // namespace
 
 // =================================================================================================
+// Host arrays handed to mt_set / mt_reset are screened on the bit pattern before they reach the arena (the kernels are
+// built with -ffinite-math-only): `limit` = largest accepted magnitude as a float bit pattern.
+static int64_t first_unusable(const float* v, int64_t count, uint32_t limit) {
+  for (int64_t i = 0; i < count; ++i) {
+    uint32_t bits;
+    std::memcpy(&bits, v + i, 4);
+    if ((bits & 0x7FFFFFFFu) > limit) return i;
+  }
+  return -1;
+}
+constexpr uint32_t kMaxAngleBits = 0x47000000u;   // 32768.0f: the bound of unusable_angle (kernels.h)
+constexpr uint32_t kMaxFiniteBits = 0x7F7FFFFFu;  // FLT_MAX
+
 extern "C" {
 
 int mt_version(void) { return MT_VERSION; }
@@ -385,7 +410,16 @@ int mt_create(mt_handle* out, const mt_config* cfg) {
   h->trig = (cfg->flags & MT_FLAG_HW_TRIG) ? 2 : ((cfg->flags & MT_FLAG_DIRECT_TRIG) ? 1 : 0);
   if (cfg->flags & MT_FLAG_ABLATE_LOOP) h->trig = (cfg->flags & MT_FLAG_ABLATE_OBS) ? 4 : 3;
   else if (cfg->flags & MT_FLAG_ABLATE_OBS) h->trig = 5;   /* OBS alone = arithmetic-only build */
-  h->lds_table = (cfg->flags & MT_FLAG_DH_IN_LDS) != 0;
+  // The angle-addition recurrence of the interior sub-steps is run from both ends of the route, (S - 1) / 2 rotations
+  // per half.  Its drift grows with the number of rotations: measured against the fp64 oracle over 2 x 1 048 576
+  // routes per case (tests/test_gpu_zmin.py), 12 rotations (S = 25, the reference's literal, manytor.py:178) cost
+  // 3.3e-5 in z on the reference arm and 6.6e-5 on the 7-joint arm, 31 rotations (S = 64) 8.6e-5 / 1.3e-4 -- outside the
+  // 1e-4 position tolerance.  Longer routes therefore take the per-pose polynomial sincos (the MT_FLAG_DIRECT_TRIG
+  // kernels: no drift, about twice the arithmetic) instead of the recurrence.
+  constexpr int kMaxRecurrenceRotations = 12;
+  const bool long_route = h->trig == 0 && (cfg->substeps - 1) / 2 > kMaxRecurrenceRotations;
+  if (long_route) h->trig = 1;
+  h->lds_table = (cfg->flags & MT_FLAG_DH_IN_LDS) != 0 && !long_route;  // the LDS-table variant exists for the recurrence only
   // Which step kernel for which batch (tools/variant_sweep.py, profiles/r02_variants.md section 3; all variants give
   // the same bits):
   //   <= 32 768 arms   one env over 4 lanes   (4.2-5.0 us per step against 5.6-6.2)
@@ -446,7 +480,8 @@ int mt_create(mt_handle* out, const mt_config* cfg) {
                o_obs = take(3 * K * ld * 4), o_alive = take(ld * 4), o_tot = take(ld * 4), o_rew = take(ld * 4),
                o_done = take(ld), o_bits = take(ld / 64 * 8), o_ee = take(3 * ld * 4), o_epi = take(ld * 4),
                o_last = take(ld * 4), o_ring = take((size_t)cfg->return_ring * ld * 4), o_misc = take(256),
-               o_trace = take((cfg->flags & MT_FLAG_TRACE) ? (size_t)cfg->substeps * 3 * ld * 4 : 0);
+               o_trace = take((cfg->flags & MT_FLAG_TRACE) ? (size_t)cfg->substeps * 3 * ld * 4 : 0),
+               o_zmin = take((cfg->flags & MT_FLAG_DEBUG_ZMIN) ? ld * 4 : 0);
   h->arena_bytes = off;
   if (hipMalloc(&h->arena, h->arena_bytes) != hipSuccess) {
     (void)hipGetLastError();
@@ -473,6 +508,7 @@ int mt_create(mt_handle* out, const mt_config* cfg) {
   a.bad_actions = (uint32_t*)(base + o_misc);                 // word 0 of the misc block
   h->spare_bits = (unsigned long long*)(base + o_misc + 64);  // ballot sink of single-env launches
   h->trace = (cfg->flags & MT_FLAG_TRACE) ? (float*)(base + o_trace) : nullptr;
+  a.zmin = (cfg->flags & MT_FLAG_DEBUG_ZMIN) ? (float*)(base + o_zmin) : nullptr;
   a.n = h->n;
   a.ld = h->ld;
   a.env_base = cfg->env_id_base;
@@ -547,6 +583,7 @@ int mt_use_own_stream(mt_handle h) {
 
 int mt_sync(mt_handle h) {
   MT_REQUIRE(nullptr, h != nullptr, "handle is NULL");
+  MT_ON_DEVICE(h, h->cfg.device);  // the NULL stream names the CURRENT device's default stream
   MT_HIP(h, hipStreamSynchronize(h->stream));
   if (h->gather_pending) {  // a gather begun on the side stream is part of "everything queued on this handle"
     MT_HIP(h, hipStreamSynchronize(h->side_stream));
@@ -561,6 +598,10 @@ int mt_reset(mt_handle h, const float* points, int layout, int is_device) {
   MT_REQUIRE(nullptr, h != nullptr, "handle is NULL");
   MT_REQUIRE(h, points != nullptr, "points is NULL (use mt_reset_random for device-drawn targets)");
   MT_REQUIRE(h, layout == MT_ENV_MAJOR || layout == MT_SOA, "bad layout");
+  if (!is_device && layout == MT_ENV_MAJOR) {
+    const int64_t bad = first_unusable(points, h->n * 3 * h->K, kMaxFiniteBits);
+    if (bad >= 0) return fail(h, MT_ERR_INVALID_ARG, "mt_reset: points element " + std::to_string(bad) + " is NaN or infinite");
+  }
   MT_ON_DEVICE(h, h->cfg.device);
   const int rows = 3 * h->K;
   if (layout == MT_SOA) {
@@ -967,6 +1008,7 @@ static int64_t env_major_bytes(mt_handle h, int field) {
     case MT_F_JOINTS: return n * h->D * 3 * 4;
     case MT_F_RETURN_RING: return h->args.ring ? n * (int64_t)h->args.ring_slots * 4 : -1;
     case MT_F_TRACE: return h->trace ? n * (int64_t)h->cfg.substeps * 3 * 4 : -1;
+    case MT_F_ZMIN: return h->args.zmin ? n * 4 : -1;
     default: return -1;
   }
 }
@@ -1004,6 +1046,7 @@ int mt_get(mt_handle h, int field, void* dst, int64_t dst_bytes, int is_device) 
     case MT_F_LAST_RETURN: direct = true; direct_src = a.last_return; break;
     case MT_F_DONE: direct = true; direct_src = a.done; break;
     case MT_F_DONE_BITS: direct = true; direct_src = a.done_bits; break;
+    case MT_F_ZMIN: direct = true; direct_src = a.zmin; break;
     default: return fail(h, MT_ERR_INVALID_ARG, "unknown field");
   }
   if (direct) {
@@ -1021,15 +1064,31 @@ int mt_get(mt_handle h, int field, void* dst, int64_t dst_bytes, int is_device) 
 int mt_set(mt_handle h, int field, const void* src, int64_t src_bytes) {
   MT_REQUIRE(nullptr, h != nullptr, "handle is NULL");
   MT_REQUIRE(h, src != nullptr, "src is NULL");
-  MT_REQUIRE(h, field == MT_F_GOALS || field == MT_F_POINTS || field == MT_F_ALIVE || field == MT_F_TOTAL_REWARD,
+  MT_REQUIRE(h, field == MT_F_GOALS || field == MT_F_POINTS || field == MT_F_ALIVE || field == MT_F_TOTAL_REWARD ||
+                    field == MT_F_DONE || field == MT_F_EPISODES || field == MT_F_LAST_RETURN || field == MT_F_RETURN_RING,
              "field is not settable");
   const int64_t need = env_major_bytes(h, field);
+  MT_REQUIRE(h, need > 0, "the handle was created without this field");
   MT_REQUIRE(h, src_bytes == need, "src_bytes does not match the field's env-major size");
+  if (field == MT_F_GOALS || field == MT_F_POINTS || field == MT_F_TOTAL_REWARD || field == MT_F_LAST_RETURN ||
+      field == MT_F_RETURN_RING) {
+    const int64_t bad = first_unusable((const float*)src, need / 4, field == MT_F_GOALS ? kMaxAngleBits : kMaxFiniteBits);
+    if (bad >= 0)
+      return fail(h, MT_ERR_INVALID_ARG, "mt_set: element " + std::to_string(bad) + " is NaN, infinite or (joint angles) beyond "
+                                         "+-32768 degrees");
+  }
   MT_ON_DEVICE(h, h->cfg.device);
   const dim3 g = grid_for(h->n), b(kBlock);
   const StepArgs& a = h->args;
-  if (field == MT_F_TOTAL_REWARD) {
-    MT_HIP(h, hipMemcpyAsync(a.total_reward, src, (size_t)need, hipMemcpyHostToDevice, h->stream));
+  void* row = field == MT_F_TOTAL_REWARD ? (void*)a.total_reward : field == MT_F_DONE ? (void*)a.done :
+              field == MT_F_EPISODES ? (void*)a.episodes : field == MT_F_LAST_RETURN ? (void*)a.last_return : nullptr;
+  if (row) {  // single-row fields: env-major == SoA
+    MT_HIP(h, hipMemcpyAsync(row, src, (size_t)need, hipMemcpyHostToDevice, h->stream));
+    if (field == MT_F_DONE) {
+      hipLaunchKernelGGL(done_bits_rebuild_kernel, g, b, 0, h->stream, a.done, h->n, a.done_bits);
+      int rc = check_launch(h, "done_bits_rebuild_kernel");
+      if (rc) return rc;
+    }
   } else {
     int rc = ensure_staging(h, (size_t)need);
     if (rc) return rc;
@@ -1038,12 +1097,20 @@ int mt_set(mt_handle h, int field, const void* src, int64_t src_bytes) {
       hipLaunchKernelGGL((env_major_to_soa<float>), g, b, 0, h->stream, (const float*)h->staging, h->D, h->n, a.goals, h->ld);
     else if (field == MT_F_POINTS)
       hipLaunchKernelGGL((env_major_to_soa<float>), g, b, 0, h->stream, (const float*)h->staging, 3 * h->K, h->n, a.points, h->ld);
+    else if (field == MT_F_RETURN_RING)
+      hipLaunchKernelGGL((env_major_to_soa<float>), g, b, 0, h->stream, (const float*)h->staging, (int)a.ring_slots, h->n, a.ring, h->ld);
     else
       hipLaunchKernelGGL(alive_pack, g, b, 0, h->stream, (const uint8_t*)h->staging, h->K, h->n, a.alive);
     rc = check_launch(h, "mt_set");
     if (rc) return rc;
   }
   MT_HIP(h, hipStreamSynchronize(h->stream));
+  return MT_OK;
+}
+
+int mt_set_episode_base(mt_handle h, uint32_t episode0) {
+  MT_REQUIRE(nullptr, h != nullptr, "handle is NULL");
+  h->args.episode0 = episode0;
   return MT_OK;
 }
 

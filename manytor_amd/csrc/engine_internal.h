@@ -42,6 +42,8 @@ struct mt_engine {
   hipStream_t side_stream = nullptr;
   hipEvent_t ev_snap = nullptr, ev_g0 = nullptr, ev_g1 = nullptr;
   float* snap = nullptr;
+  void* reduce_scratch = nullptr;  // mt_reduce_returns: block partials + per-rank records, grown on demand
+  size_t reduce_scratch_bytes = 0;
   bool reset_split = false;  // mt_reset_random / mt_reset_done of the whole batch: reset_split_kernel
   // mt_rollout on small batches: the segment's launches are captured once into a HIP graph and replayed
   struct RolloutGraph {

@@ -699,6 +699,7 @@ __global__ __launch_bounds__(kBlock, (PF ? 1 : step_min_waves<Tbl, TRIG>())) voi
   float el[3], e[3];
   const float zmin = route_kinematics<Tbl, TRIG>(t, a.S, a.inv_sm1, g, act, el, e);
   const bool ground = zmin < 0.f;  // manytor.py:191
+  if (a.zmin) str_stream(a.zmin, i * 4u, zmin);  // MT_FLAG_DEBUG_ZMIN: wave-uniform branch on an SGPR pointer, NULL by default
   if (kLean && !PF) {
     am = ldr(a.alive, i * 4u);
     total_in = ldr(a.total_reward, i * 4u);
@@ -895,6 +896,7 @@ __global__ __launch_bounds__(kBlock) void step_split_kernel(const StepArgs a) {
   float el[3], e[3];
   const float zmin = route_kinematics_split<Tbl, L, false>(t, a.S, a.inv_sm1, g, act, (q & 1u) != 0, el, e);
   const bool ground = zmin < 0.f;  // manytor.py:191
+  if (a.zmin && live && q == 0) __builtin_nontemporal_store(zmin, a.zmin + i);  // MT_FLAG_DEBUG_ZMIN
 
   // ---- this sub-lane's targets ------------------------------------------------------------------------------
   uint32_t nam = am;
@@ -1011,6 +1013,13 @@ __global__ __launch_bounds__(64) void done_bits_word_kernel(const uint8_t* done,
   const int64_t i = word * 64 + threadIdx.x;
   const unsigned long long bits = __ballot(i < n && done[i] != 0);
   if (threadIdx.x == 0) done_bits[word] = bits;
+}
+
+// All done_bits words rebuilt from the done bytes (mt_set(MT_F_DONE): restoring a checkpoint).
+__global__ __launch_bounds__(kBlock) void done_bits_rebuild_kernel(const uint8_t* done, int64_t n, unsigned long long* done_bits) {
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  const unsigned long long bits = __ballot(i < n && done[i] != 0);
+  if ((threadIdx.x & 63) == 0 && (int64_t)i < n) done_bits[i >> 6] = bits;
 }
 
 // One rejection-sampling candidate of manytor.py:229-239: half HALF of a Philox block (philox.h: two candidates
@@ -1275,6 +1284,7 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(const StepArgs a, const
     const float zmin = route_kinematics<Tbl, 0, true, kTable>(t, a.S, a.inv_sm1, g, act, el, e, &pose, pose_valid, trig);
     pose_valid = true;
     const bool ground = zmin < 0.f;
+    if (a.zmin) str_stream(a.zmin, i * 4u, zmin);  // MT_FLAG_DEBUG_ZMIN (a step output like reward: the last step's stays)
 
     uint32_t nam = am;
     for (int k = 0; k < a.K; ++k) {
@@ -1396,6 +1406,7 @@ __global__ __launch_bounds__(kBlock) void rollout_split_kernel(const StepArgs a,
     const float zmin = route_kinematics_split<Tbl, L, true, kTable>(t, a.S, a.inv_sm1, g, act, backward, el, e, &pose, pose_valid, trig);
     pose_valid = true;
     const bool ground = zmin < 0.f;
+    if (a.zmin && live && q == 0) __builtin_nontemporal_store(zmin, a.zmin + i);  // MT_FLAG_DEBUG_ZMIN
 
     uint32_t nam = am;
     for (int p = (int)q; p < a.K; p += L) {

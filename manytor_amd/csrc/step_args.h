@@ -36,6 +36,7 @@ struct StepArgs {
   float* last_return;             // [ld] return of the episode that ended at the last (auto-)reset
   float* ring;                    // [ring_slots][ld] returns of the episodes an env finished, slot = finished count % ring_slots
   uint32_t* bad_actions;          // [1] number of (env, step) pairs whose staged action was not a usable angle
+  float* zmin;                    // [ld] MT_FLAG_DEBUG_ZMIN only (else NULL): the z-minimum the ground test of the last step used
   uint32_t ring_slots, episode0;  // episode0 = episode index every env got at the last full reset
   int64_t n, ld, env_base;
   int32_t K, S;

@@ -61,11 +61,20 @@ def init_process_group(backend=None, device=None):
 
 def exchange_unique_id(make_id, rank: int, group=None) -> bytes:
     """Rank 0 calls `make_id()` (-> 128 bytes naming a new RCCL communicator); every rank returns those bytes.
-    Shipped through the torch.distributed process group (any backend), i.e. the rendezvous torchrun already set up."""
+    Shipped through the torch.distributed process group (any backend), i.e. the rendezvous torchrun already set up.
+    If `make_id` fails on rank 0 (librccl not loadable, ncclGetUniqueId error) the failure travels in the SAME
+    broadcast, so every rank raises together instead of rank 0 leaving its peers blocked in the collective."""
     import torch.distributed as dist
-    box = [make_id() if rank == 0 else None]
+    box = [None]
+    if rank == 0:
+        try:
+            box = [(bytes(make_id()), None)]
+        except Exception as e:                 # noqa: BLE001 -- shipped to every rank below
+            box = [(None, f"{type(e).__name__}: {e}")]
     dist.broadcast_object_list(box, src=0, group=group)
-    uid = bytes(box[0])
+    uid, err = box[0]
+    if uid is None:
+        raise RuntimeError(f"rank 0 could not create the RCCL unique id ({err})")
     if len(uid) != 128:
         raise RuntimeError(f"unique id has {len(uid)} bytes, expected 128")
     return uid

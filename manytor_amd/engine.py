@@ -63,7 +63,8 @@ class StepEngine:
 
     def __init__(self, n_envs, obj_number=10, dh_table=REF_DH_TABLE, substeps=25, pickup_tol=8.0, radius=51.3,
                  device=0, env_id_base=0, terminate_on_ground=False, hw_trig=False, dh_in_lds=False,
-                 direct_trig=False, specialize=True, ablate=0, return_ring=4, trace=False, obs_frame=-2, ee_frame=-1):
+                 direct_trig=False, specialize=True, ablate=0, return_ring=4, trace=False, obs_frame=-2, ee_frame=-1,
+                 debug_zmin=False):
         self._lib = L.load()
         table = np.asarray(dh_table, dtype=np.float64)
         if table.ndim != 2 or table.shape[1] != 4:
@@ -86,6 +87,7 @@ class StepEngine:
         cfg.flags = ((L.FLAG_TERMINATE_ON_GROUND if terminate_on_ground else 0) | (L.FLAG_HW_TRIG if hw_trig else 0)
                      | (L.FLAG_DH_IN_LDS if dh_in_lds else 0) | (L.FLAG_DIRECT_TRIG if direct_trig else 0)
                      | (0 if specialize else L.FLAG_NO_SPECIALIZE) | (L.FLAG_TRACE if trace else 0)
+                     | (L.FLAG_DEBUG_ZMIN if debug_zmin else 0)
                      | (L.FLAG_ABLATE_LOOP if ablate in (1, 2) else 0) | (L.FLAG_ABLATE_OBS if ablate in (2, 3) else 0))
         cfg.pickup_tol = float(pickup_tol)
         cfg.radius = float(radius)
@@ -346,6 +348,7 @@ class StepEngine:
             L.F_TOTAL_REWARD: ((n,), np.float32), L.F_JOINTS: ((n, d, 3), np.float32),
             L.F_EPISODES: ((n,), np.uint32), L.F_LAST_RETURN: ((n,), np.float32),
             L.F_RETURN_RING: ((n, self.return_ring_slots), np.float32), L.F_TRACE: ((n, self.substeps, 3), np.float32),
+            L.F_ZMIN: ((n,), np.float32),
         }[field]
 
     def get(self, field) -> np.ndarray:
@@ -389,14 +392,20 @@ class StepEngine:
 
     # ---- checkpoint / resume (the reference keeps its state in attributes, manytor.py:131-139) --------
     def get_state(self) -> dict:
-        """Host copy of everything a step depends on: joint angles, targets, alive flags, returns (+ the step outputs
-        a caller may want to keep).  set_state() of this dict on an engine of the same shape resumes bit-identically."""
-        return {"goals": self.goals(), "points": self.points(), "alives": self.alives(), "total_reward": self.total_reward(),
-                "obs": self.obs(), "reward": self.reward(), "done": self.done(), "ee": self.ee(),
-                "episodes": self.episodes(), "last_return": self.last_return()}
+        """Host copy of everything later calls depend on: joint angles, targets, alive flags, returns, done flags,
+        per-env episode counters, last returns, the return ring and the episode base (+ the step outputs a caller may
+        want to keep).  set_state() of this dict on an engine of the same shape resumes bit-identically: step(),
+        reset_done(), finished() and return_ring() all continue as in the original run."""
+        st = {"goals": self.goals(), "points": self.points(), "alives": self.alives(), "total_reward": self.total_reward(),
+              "obs": self.obs(), "reward": self.reward(), "done": self.get(L.F_DONE), "ee": self.ee(),
+              "episodes": self.episodes(), "last_return": self.last_return(), "episode0": int(self.episode0)}
+        if self.return_ring_slots:
+            st["return_ring"] = self.return_ring()
+        return st
 
     def set_state(self, state: dict):
-        """Restore goals / points / alives / total_reward from get_state() (or any arrays of those shapes)."""
+        """Restore from get_state(): goals / points / alives / total_reward, and -- when present -- the raw done bytes
+        (incl. 2 = finished and already re-armed), episode counters, last returns, return ring and episode base."""
         if not getattr(self, "_armed", False):
             # a fresh handle has to be reset once before it can step; the values are overwritten right below
             self.reset(np.asarray(state["points"], dtype=np.float32))
@@ -404,6 +413,14 @@ class StepEngine:
         self.set(L.F_GOALS, state["goals"])
         self.set(L.F_ALIVE, np.asarray(state["alives"]).astype(np.uint8))
         self.set(L.F_TOTAL_REWARD, state["total_reward"])
+        for key, field in (("done", L.F_DONE), ("episodes", L.F_EPISODES), ("last_return", L.F_LAST_RETURN)):
+            if key in state:
+                self.set(field, state[key])
+        if "return_ring" in state and self.return_ring_slots:
+            self.set(L.F_RETURN_RING, state["return_ring"])
+        if "episode0" in state:
+            self.episode0 = int(state["episode0"])
+            self._call(self._lib.mt_set_episode_base, C.c_uint32(self.episode0))
 
     # convenience getters in the reference's vocabulary
     def goals(self):
@@ -458,6 +475,11 @@ class StepEngine:
     def finished(self):
         """(N,) number of episodes each env has finished (re-armed by reset_done / auto_reset) since the last full reset."""
         return (self.episodes() - np.uint32(self.episode0)).astype(np.int64)
+
+    def zmin(self):
+        """(N,) signed minimum z of the observation / pickup frames over all sub-step poses of the last step: the value
+        the kernel's ground test compared with 0 (needs debug_zmin=True; manytor.py:191-192)."""
+        return self.get(L.F_ZMIN)
 
     def trace(self):
         """(N, S, 3): end effector at each sub-step pose of the last step (needs trace=True; manytor.py:190)."""

@@ -35,7 +35,7 @@ def load():
         dp, u8p, i32p = C.POINTER(C.c_double), C.POINTER(C.c_uint8), C.POINTER(C.c_int32)
         lib.mto_step.restype = None
         lib.mto_step.argtypes = [C.c_int64, C.c_int, C.c_int, C.c_int, C.c_double, dp, dp, dp, u8p, dp, dp, dp, i32p, u8p,
-                                 dp, dp, dp, C.c_int, C.c_int, C.c_int]
+                                 dp, dp, dp, C.c_int, C.c_int, C.c_int, dp]
         lib.mto_observe.restype = None
         lib.mto_observe.argtypes = [C.c_int64, C.c_int, C.c_int, dp, dp, dp, u8p, dp, C.c_int, C.c_int]
         lib.mto_max_threads.restype = C.c_int
@@ -69,6 +69,7 @@ class COracle:
         self.ground_margin = np.full(self.n, np.inf)
         self.pickup_margin = np.full((self.n, self.k), np.inf)
         self.ground_hit = np.zeros(self.n, dtype=bool)
+        self.zmin = np.full(self.n, np.inf)      # signed min z of the two tested frames over the last step's poses
 
     @property
     def alives(self):
@@ -98,6 +99,6 @@ class COracle:
                           _p(self.total_reward, C.c_double), _p(act, C.c_double), _p(obs2, C.c_double),
                           _p(reward, C.c_int32), _p(done, C.c_uint8), _p(self.joints_coordinates, C.c_double),
                           _p(self.ground_margin, C.c_double), _p(self.pickup_margin, C.c_double), self.threads,
-                          self.fo, self.fe)
+                          self.fo, self.fe, _p(self.zmin, C.c_double))
         self.ground_hit = reward == -1
         return obs2, reward.astype(np.int64), done.astype(bool)

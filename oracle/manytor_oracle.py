@@ -272,6 +272,7 @@ class BatchOracle:
         self.ground_margin = np.full(self.n, np.inf)
         self.pickup_margin = np.full((self.n, self.k), np.inf)
         self.ground_hit = np.zeros(self.n, dtype=bool)
+        self.zmin = np.full(self.n, np.inf)      # signed min z of the two tested frames over the last step's poses
 
     def reset(self, points):
         """manytor.py:219-253 with the targets supplied by the caller."""
@@ -307,6 +308,7 @@ class BatchOracle:
         step = (actions - start) / (self.substeps - 1)  # np.linspace arithmetic
         ground = np.zeros(self.n, dtype=bool)
         margin = np.full(self.n, np.inf)
+        zmin = np.full(self.n, np.inf)
         for k in range(self.substeps):
             pose = actions if k == self.substeps - 1 else start + k * step
             jc = batch_joints_coordinates(pose, self.table, self.dtype)
@@ -314,6 +316,7 @@ class BatchOracle:
             z3 = jc[:, self.ee_frame, 2]
             ground |= (z2 < 0) | (z3 < 0)
             margin = np.minimum(margin, np.minimum(np.abs(z2), np.abs(z3)))
+            zmin = np.minimum(zmin, np.minimum(z2, z3))
         self.goals = actions.copy()
         self.joints_coordinates = jc
         obs2 = self.get_observations()                  # before pickup, manytor.py:204
@@ -324,6 +327,7 @@ class BatchOracle:
         done = ~self.alives.any(axis=1)
         self.ground_hit = ground
         self.ground_margin = margin
+        self.zmin = zmin
         return obs2, reward, done
 
 

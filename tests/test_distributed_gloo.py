@@ -78,6 +78,33 @@ def test_gather_layout_world2_gloo(n_total):
     assert uid == bytes(range(128))
 
 
+def _failing_id_worker(rank, world, port, q):
+    r, _, w = _init(rank, world, port)
+
+    def make_id():
+        raise OSError("librccl.so: cannot open shared object file")
+    try:
+        D.exchange_unique_id(make_id, r)
+        msg = None
+    except RuntimeError as e:
+        msg = str(e)
+    # every rank left the SAME broadcast, so the next collective lines up (rank 0 used to raise before the
+    # broadcast and its peers stayed blocked in it)
+    flag = torch.tensor([0 if msg is None else 1], dtype=torch.int32)
+    dist.all_reduce(flag, op=dist.ReduceOp.SUM)
+    if r == 0:
+        q.put((msg, int(flag.item())))
+    else:
+        assert msg is not None and "cannot open shared object" in msg
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_unique_id_failure_on_rank0_raises_on_every_rank():
+    msg, raised = _spawn(_failing_id_worker, ())
+    assert raised == 2 and "rank 0 could not create the RCCL unique id" in msg and "cannot open shared object" in msg
+
+
 def test_gather_single_process_is_identity():
     t = torch.arange(10, dtype=torch.float32)
     assert torch.equal(D.gloo_gather_returns(t, 10), t)

@@ -310,3 +310,87 @@ def test_checkpoint_and_resume_is_bit_identical(m):
     a.set_state(snap)                                        # and back in time on the same engine
     a.rollout(6, 4, 9)
     np.testing.assert_array_equal(a.obs(), want["obs"])
+
+
+def test_checkpoint_restores_done_flags_episode_counters_and_the_ring(m):
+    """a checkpoint taken while envs are finished (done = 1), re-armed in-kernel (done = 2) or several
+    episodes in must resume reset_done() / finished() / return_ring() exactly as the original run would."""
+    n, k = 20000, 1
+    a = m.StepEngine(n, k, pickup_tol=30.0, return_ring=4)
+    a.reset_random(12, 7)                                    # episode base 7
+    a.rollout_fused(20, 12, 0, auto_reset=True)              # envs finish, some several times; some end with done == 2
+    a.rollout(3, 12, 20)                                     # ... and some are finished-and-waiting (done == 1)
+    snap = a.get_state()
+    assert (snap["done"] == 1).any() and snap["episodes"].max() >= 9 and snap["episode0"] == 7
+
+    def carry_on(e):
+        e.reset_done(12)
+        e.rollout(4, 12, 23)
+        e.reset_done(12)
+        e.rollout_fused(6, 12, 27, auto_reset=True)
+        return {**e.get_state(), "finished": e.finished(), "done_bits": e.done_bits()}
+    want = carry_on(a)
+    b = m.StepEngine(n, k, pickup_tol=30.0, return_ring=4)   # fresh engine, never reset
+    b.set_state(snap)
+    np.testing.assert_array_equal(b.get(m.lib.F_DONE), snap["done"])
+    bits = b.done_bits()
+    unpacked = ((bits[:, None] >> np.arange(64, dtype=np.uint64)) & np.uint64(1)).astype(bool).ravel()[:n]
+    np.testing.assert_array_equal(unpacked, snap["done"] != 0)           # ballot words rebuilt from the bytes
+    got = carry_on(b)
+    for key, v in want.items():
+        np.testing.assert_array_equal(got[key], v, err_msg=key)
+    assert want["finished"].max() >= 3
+
+
+def test_mt_set_screens_non_finite_values(m):
+    """the kernels are built with -ffinite-math-only, so NaN / inf must not reach the arena through
+    attribute assignment either; joint angles beyond +-32768 degrees are refused like staged actions are."""
+    e = m.StepEngine(8, 2)
+    e.reset_random(1, 0)
+    goals, pts = e.goals(), e.points()
+    for field, good, bad_value in ((m.lib.F_GOALS, goals, np.nan), (m.lib.F_GOALS, goals, 1e6), (m.lib.F_POINTS, pts, np.inf),
+                                   (m.lib.F_TOTAL_REWARD, e.total_reward(), -np.inf)):
+        bad = good.copy()
+        bad.flat[3] = bad_value
+        with pytest.raises(ValueError):
+            e.set(field, bad)
+        np.testing.assert_array_equal(e.get(field), good)    # nothing was written
+    with pytest.raises(ValueError):
+        e.reset(np.full((8, 2, 3), np.nan, dtype=np.float32))
+
+
+def test_single_env_reset_draws_fresh_targets_and_leaves_the_counters_alone(m):
+    """environment[i].reset() with the device RNG must give NEW targets at every call (manytor.py:229 draws
+    anew), must not make finished() count an episode, and must not collide with the next whole-batch reset."""
+    me = m.Multienv((4, 4), 3, rng="device", seed=77)
+    me.reset()
+    e5 = me.environment[5]
+    p0 = e5.points.copy()
+    e5.reset()
+    p1 = e5.points.copy()
+    e5.reset()
+    p2 = e5.points.copy()
+    assert not np.array_equal(p0, p1) and not np.array_equal(p1, p2) and not np.array_equal(p0, p2)
+    for p in (p1, p2):
+        assert (p[:, 2] >= 0).all() and (np.linalg.norm(p, axis=1) <= 51.3 * (1 + 1e-6)).all()
+    assert not me.engine.finished().any()                    # nobody finished an episode
+    others = np.arange(16) != 5
+    before = me.engine.points()
+    me.reset()                                               # next whole-batch reset: env 5 gets the batch's episode key
+    from oracle import philox_ref as px
+    np.testing.assert_array_equal(me.engine.points(), px.sample_targets(77, np.arange(16, dtype=np.uint64), 1, 3, 51.3))
+    assert not np.array_equal(me.engine.points()[others], before[others])
+
+
+def test_environment_keeps_its_pose_mirror_when_the_kernel_rejects_an_action(m):
+    env = m.Environment(3)
+    np.random.seed(1)
+    env.reset()
+    env.step([10, 20, 30, 40])
+    env.step([np.nan, 0, 0, 0])                              # rejected: the arm holds [10, 20, 30, 40]
+    np.testing.assert_array_equal(env.goals, [10, 20, 30, 40])
+    np.testing.assert_array_equal(env._pose[0], [10, 20, 30, 40])
+    env.step([0, 0, 0, 0])
+    tr = env.trajectory                                      # 1 seed row + 3 routes x 25 sub-steps
+    assert tr.shape == (76, 3)
+    np.testing.assert_allclose(tr[26:51], np.repeat(tr[25:26], 25, axis=0), atol=1e-5)   # the held step did not move

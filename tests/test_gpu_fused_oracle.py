@@ -8,7 +8,8 @@ mt_rollout_fused(auto_reset) / mt_reset_done do (return -> ring, episode + 1, ze
 
 An env is compared only while the oracle's own decision margins (z = 0 of the ground flag, |delta| = tol of a pickup)
 stay above GUARD at EVERY step of the rollout: inside the band fp32 and fp64 may legitimately decide differently, and
-in a fused rollout the two sides cannot be re-synchronised mid-way.  The clean fraction is asserted to stay high.
+in a fused rollout the two sides cannot be re-synchronised mid-way.  The clean fraction of every case is measured,
+recorded and asserted against that measurement (minus two points).
 """
 import numpy as np
 import pytest
@@ -33,6 +34,22 @@ def _tables(m):
     rt5 = np.column_stack([rng.uniform(0, 9, 5), rng.choice([-np.pi / 2, 0.3, np.pi / 2], 5), rng.uniform(2, 12, 5),
                            np.zeros(5)])
     return {"ref": (m.REF_DH_TABLE, 51.3), "dh7": (m.DH7_TABLE, 92.6), "rt5": (rt5, 40.0)}
+
+
+def record_clean(*row):
+    """The measured clean fraction of every case goes to gpurun_out/ (scratch): the floors asserted below are these
+    measurements minus two points, not a guess."""
+    import json
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "fused_clean_fraction.jsonl")
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "a") as f:
+            f.write(json.dumps(dict(zip(("table", "n", "k", "T", "auto_reset", "tol", "clean"), row))) + "\n")
+    except OSError:
+        pass
+    print(f"[fused-vs-oracle] {row[0]} n={row[1]} K={row[2]} T={row[3]} auto_reset={row[4]} tol={row[5]}: "
+          f"clean fraction {row[6]:.4f}")
 
 
 def run_fused_against_oracle(m, n, k, table_name, T, auto_reset, tol, seed, min_clean):
@@ -72,6 +89,7 @@ def run_fused_against_oracle(m, n, k, table_name, T, auto_reset, tol, seed, min_
             ora.points[idx] = px.sample_targets(seed, ids[idx], episodes[idx], k, radius).astype(np.float64)
 
     c = clean
+    record_clean(table_name, n, k, T, auto_reset, tol, float(c.mean()))
     assert c.mean() >= min_clean, c.mean()
     # state after the rollout
     np.testing.assert_array_equal(eng.goals()[c], ora.goals[c].astype(np.float32))
@@ -100,25 +118,43 @@ def run_fused_against_oracle(m, n, k, table_name, T, auto_reset, tol, seed, min_
     return dict(clean=float(c.mean()), finished=int((episodes > 0).sum()), max_episodes=int(episodes.max()))
 
 
-@pytest.mark.parametrize("table_name,T,auto_reset,tol", [
-    ("ref", 50, False, 8.0),      # BASELINE.json configs[2]: one full 50-step episode (test_multi.py:8)
-    ("ref", 50, True, 20.0),      # wide pickup box: many envs finish (several times) inside the launch
-    ("dh7", 25, False, 8.0),      # configs[4]
-    ("dh7", 25, True, 45.0),
+# `floor` = the clean fraction MEASURED for the case (round 3, profiles/r03_fused_clean_fraction.jsonl; the inputs are
+# seeded, so it is reproducible) minus two points: the comparison covers this share of the envs, stated, not guessed.
+@pytest.mark.parametrize("table_name,T,auto_reset,tol,floor", [
+    ("ref", 50, False, 8.0, 0.9075),      # BASELINE.json configs[2]: one full 50-step episode (test_multi.py:8); measured 0.9275
+    ("ref", 50, True, 20.0, 0.9314),      # wide pickup box: many envs finish (several times) inside the launch; 0.9514
+    ("dh7", 25, False, 8.0, 0.9536),      # configs[4]; 0.9736
+    ("dh7", 25, True, 45.0, 0.9647),      # 0.9847
 ])
-def test_fused_rollout_every_env_against_the_c_oracle_full_size(m, table_name, T, auto_reset, tol):
-    stats = run_fused_against_oracle(m, 1048576, 7, table_name, T, auto_reset, tol, seed=0xF00D + T, min_clean=0.85)
+def test_fused_rollout_every_env_against_the_c_oracle_full_size(m, table_name, T, auto_reset, tol, floor):
+    stats = run_fused_against_oracle(m, 1048576, 7, table_name, T, auto_reset, tol, seed=0xF00D + T, min_clean=floor)
     if auto_reset:
         assert stats["finished"] > 1000, stats                     # the re-arm path was really exercised
 
 
-@pytest.mark.parametrize("n,k,table_name,T,auto_reset,tol", [
-    (100003, 3, "ref", 40, True, 25.0),       # ragged size (prime), few targets: envs finish up to several times
-    (65537, 7, "rt5", 12, False, 8.0),        # runtime-table kernel, one past a power of two
-    (777, 32, "ref", 30, True, 30.0),         # K = 32: the 96 KB LDS tile of the fused kernel
+@pytest.mark.parametrize("n,table_name,auto_reset,tol,kernel,floor", [
+    (65536, "ref", False, 8.0, "L=2", 0.9401),      # BASELINE.json configs[1]: rollout_split_kernel<Ref4Table, 2>; measured 0.9601
+    (65536, "dh7", True, 45.0, "L=2", 0.9649),      # 0.9849
+    (131072, "ref", True, 20.0, "pf=8", 0.9532),    # the per-GPU shard of 1 M arms over 8 GPUs: rollout_kernel, one env per lane; 0.9732
+    (131072, "dh7", False, 8.0, "pf=8", 0.9530),    # 0.9730
+    (32768, "ref", True, 20.0, "L=4", 0.9542),      # rollout_split_kernel<.., 4>; 0.9742
 ])
-def test_fused_rollout_against_the_c_oracle_ragged_and_generic(m, n, k, table_name, T, auto_reset, tol):
-    stats = run_fused_against_oracle(m, n, k, table_name, T, auto_reset, tol, seed=31 + n, min_clean=0.5)
+def test_fused_rollout_every_env_against_the_c_oracle_at_each_dispatch_regime(m, n, table_name, auto_reset, tol, kernel, floor):
+    probe = m.StepEngine(n, 7, dh_table=_tables(m)[table_name][0], radius=_tables(m)[table_name][1])
+    assert kernel in probe.step_kernel_name(), probe.step_kernel_name()    # the split / one-lane choice is shared with the rollout
+    probe.close()
+    stats = run_fused_against_oracle(m, n, 7, table_name, 25, auto_reset, tol, seed=0xD15 + n, min_clean=floor)
+    if auto_reset:
+        assert stats["finished"] > 100, stats
+
+
+@pytest.mark.parametrize("n,k,table_name,T,auto_reset,tol,floor", [
+    (100003, 3, "ref", 40, True, 25.0, 0.9475),       # ragged size (prime), few targets: envs finish up to several times; measured 0.9675
+    (65537, 7, "rt5", 12, False, 8.0, 0.9572),        # runtime-table kernel, one past a power of two; 0.9772
+    (777, 32, "ref", 30, True, 30.0, 0.9247),         # K = 32: the 96 KB LDS tile of the fused kernel; 0.9447
+])
+def test_fused_rollout_against_the_c_oracle_ragged_and_generic(m, n, k, table_name, T, auto_reset, tol, floor):
+    stats = run_fused_against_oracle(m, n, k, table_name, T, auto_reset, tol, seed=31 + n, min_clean=floor)
     if auto_reset and k <= 3:
         assert stats["max_episodes"] >= 2, stats
 
