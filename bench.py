@@ -69,11 +69,47 @@ def usable_cores():
     return cores, why
 
 
-def cpu_baseline(dof_table, k, budget_s=12.0, n=65536):
+def numpy_multiprocess_baseline(dof, k, workers, budget_s=3.0, shard=16384, timeout_s=120.0):
+    """vectorised numpy fanned out over `workers` processes (oracle/numpy_shard_worker.py, one per usable
+    core, plain subprocesses).  All workers finish their start-up, are released together, and step for ~budget_s; the
+    figure is total env-steps / the slowest worker's stepping time.  Returns (value or None, description)."""
+    import subprocess
+    procs = []
+    try:
+        for w in range(workers):
+            procs.append(subprocess.Popen([sys.executable, "-m", "oracle.numpy_shard_worker", str(w), str(shard), str(dof), str(k),
+                                           str(budget_s)], cwd=ROOT, stdin=subprocess.PIPE, stdout=subprocess.PIPE,
+                                          stderr=subprocess.DEVNULL, text=True))
+        deadline = time.monotonic() + timeout_s
+        for p_ in procs:
+            line = p_.stdout.readline()
+            if line.strip() != "ready" or time.monotonic() > deadline:
+                raise RuntimeError("a worker did not come up")
+        for p_ in procs:
+            p_.stdin.write("go\n")
+            p_.stdin.flush()
+        res = []
+        for p_ in procs:
+            out, _ = p_.communicate(timeout=max(1.0, deadline - time.monotonic()))
+            res.append(json.loads(out.strip().splitlines()[-1]))
+        slowest = max(r["seconds"] for r in res)
+        total = sum(r["env_steps"] for r in res)
+        return total / slowest, (f"{workers} processes x {shard} envs x {res[0]['env_steps'] // shard} steps (worker 0), oracle "
+                                 f"BatchOracle fp64 (numpy), slowest worker {slowest:.1f} s")
+    except Exception as e:                                   # noqa: BLE001 -- a baseline leg must not take the bench down
+        return None, f"failed: {type(e).__name__}: {e}"
+    finally:
+        for p_ in procs:
+            if p_.poll() is None:
+                p_.kill()
+
+
+def cpu_baseline(dof_table, k, budget_s=4.0, n=65536):
     """The CPU port of the step path (oracle/: parity-checked against the reference's fixtures), timed on this box's
-    host cores on a bounded sample of the same workload.  Headline figure: the C restatement with OpenMP on every
-    core this process may use; beside it the vectorised-numpy and the scalar (reference-shaped) Python figures on one
-    core.  Baseline, not the target."""
+    host cores on a bounded sample of the same workload (about 10 s in all).  Headline figure: the C restatement with
+    OpenMP on every core this process may use; beside it the reference's own shape of CPU parallelism -- vectorised numpy,
+    env shards fanned out over all usable cores with multiprocessing -- and the one-core vectorised-numpy
+    and scalar (reference-shaped) Python figures.  Baseline, not the target."""
     from oracle import c_oracle
     from oracle import manytor_oracle as mo
     from oracle import philox_ref as px
@@ -97,24 +133,27 @@ def cpu_baseline(dof_table, k, budget_s=12.0, n=65536):
         cora.step(cacts[csteps % 4])
         csteps += 1
     dt_c = time.perf_counter() - t0
+    del cora, cacts
     # (b) vectorised numpy, one core
     ids = np.arange(n, dtype=np.uint64)
     ora = mo.BatchOracle(n, k, table=table)
     ora.reset(pts[:n])
-    acts = [px.sample_actions(0x5EED, ids, t, dof).astype(np.float64) for t in range(16)]
+    acts = [px.sample_actions(0x5EED, ids, t, dof).astype(np.float64) for t in range(8)]
     ora.step(acts[0])
     t0 = time.perf_counter()
     steps = 0
-    while steps < 2 or (time.perf_counter() - t0 < budget_s / 3 and steps < 15):
+    while steps < 2 or (time.perf_counter() - t0 < budget_s / 2 and steps < 7):
         ora.step(acts[1 + steps])
         steps += 1
     dt = time.perf_counter() - t0
+    # (b') the same, env shards over all usable cores, one process each
+    mp_value, mp_sample = numpy_multiprocess_baseline(dof, k, threads, budget_s=budget_s * 0.75)
     # (c) the reference's own shape of the computation: one env at a time, three FK chains per sub-step (manytor.py:188)
     envs = [mo.ScalarEnv(k, table=table) for _ in range(16)]
-    for e, p in zip(envs, pts[:16]):
-        e.reset(points=p)
+    for e, p_ in zip(envs, pts[:16]):
+        e.reset(points=p_)
     t1 = time.perf_counter()
-    for t in range(12):
+    for t in range(6):
         for j, e in enumerate(envs):
             e.step(acts[t][j])
     dt_scalar = time.perf_counter() - t1
@@ -123,10 +162,11 @@ def cpu_baseline(dof_table, k, budget_s=12.0, n=65536):
         "sample": f"{nc} envs x {csteps} steps, C restatement of the reference with OpenMP (oracle/manytor_oracle.c), "
                   f"{dt_c:.1f} s on {threads} threads = every core this process may use ({why}; os.cpu_count() = "
                   f"{os.cpu_count()})",
+        "numpy_multiprocess_value": mp_value, "numpy_multiprocess_cores": threads, "numpy_multiprocess_sample": mp_sample,
         "numpy_vectorised_value_1core": n * steps / dt,
         "numpy_vectorised_sample": f"{n} envs x {steps} steps, oracle BatchOracle fp64, {dt:.1f} s",
-        "scalar_faithful_value_1core": 16 * 12 / dt_scalar,
-        "scalar_faithful_sample": "16 envs x 12 steps, per-env Python loop with the reference's 75 FK chains per step "
+        "scalar_faithful_value_1core": 16 * 6 / dt_scalar,
+        "scalar_faithful_sample": "16 envs x 6 steps, per-env Python loop with the reference's 75 FK chains per step "
                                   "(oracle ScalarEnv)",
     }
 
@@ -304,6 +344,97 @@ def time_loaded_action_steps(m, n, table, radius, k, dev, seed, steps=600, episo
     return us_pair - us_sample, us_sample
 
 
+class Fabric:
+    """What a measurement needs from the process group: rank / world, a fence (own device drained, every rank arrived,
+    device idle), "rank 0 decides" and max-over-ranks.  One rank: all trivial."""
+
+    def __init__(self, rank=0, world=1, dist=None, torch=None, ctrl_dev="cpu", host_barrier=None, device_sync=None):
+        self.rank, self.world, self.dist, self.torch, self.ctrl_dev = rank, world, dist, torch, ctrl_dev
+        self.host_barrier, self.device_sync = host_barrier, device_sync or (lambda: None)
+
+    def fence(self, raw):
+        if self.world > 1:
+            # drain this rank's own queues first (incl. an exchange still running on the engine's side stream): the
+            # barrier is then passed only when every rank's device work is complete, and a collective barrier never
+            # shares the device with an exchange of the other communicator
+            raw.sync()
+            if self.host_barrier is not None:
+                self.host_barrier.wait()
+            else:
+                self.dist.barrier()
+        self.device_sync()
+
+    def rank0_says(self, flag):
+        """Time-based loops contain collectives (the gathers): every rank must run the same number of them, so rank 0's
+        clock decides for everybody."""
+        if self.world == 1:
+            return flag
+        t = self.torch.tensor([1 if flag else 0], dtype=self.torch.int32, device=self.ctrl_dev)
+        self.dist.broadcast(t, src=0)
+        return bool(int(t.item()))
+
+    def max_over_ranks(self, values):
+        if self.world == 1:
+            return np.asarray(values, dtype=np.float64)
+        t = self.torch.tensor(np.asarray(values, dtype=np.float64), dtype=self.torch.float64, device=self.ctrl_dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return t.cpu().numpy()
+
+    def any_rank(self, flag):
+        if self.world == 1:
+            return bool(flag)
+        t = self.torch.tensor([1 if flag else 0], dtype=self.torch.int32, device=self.ctrl_dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return bool(int(t.item()))
+
+
+def measure(fab, raw, n_total, steps, warmup, episode_len, seed, fused=False, overlap=True, repeats=0, prewarm_s=PREWARM_S,
+            min_timed_s=MIN_TIMED_S):
+    """The timing protocol of the contract on one engine (this rank's shard; gather already attached): time-based
+    pre-warm, `warmup` untimed steps, then `repeats` regions of EXACTLY `steps` steps, each bracketed by fence() on both
+    sides; the region time is the max over ranks, the figure the median region.  Returns a dict of raw numbers."""
+    eng = TimedEngine(raw)
+    L = max(1, min(episode_len, steps))                         # >= 1 gather inside every timed region
+    loop = EpisodeLoop(eng, seed, L, fused=fused, overlap=overlap)
+    prewarm = 0
+    fab.fence(raw)
+    t0 = time.perf_counter()
+    while fab.rank0_says(time.perf_counter() - t0 < prewarm_s):
+        loop.run(max(L, 200))
+        prewarm += max(L, 200)
+        raw.sync()
+    est_s = float(fab.max_over_ranks([(time.perf_counter() - t0) / max(1, prewarm) * steps])[0])   # one region, estimated
+    reps = repeats or int(min(100, max(5, math.ceil(min_timed_s / max(est_s, 1e-6)))))
+    loop.run(warmup)                                            # the W untimed warm-up steps of the contract
+    fab.fence(raw)
+    regions, kernel_ms, gather_ms, launches, gathers = [], 0.0, 0.0, 0, 0
+    for _ in range(reps):
+        eng.start_region()
+        fab.fence(raw)
+        t0 = time.perf_counter()
+        ln, gt = loop.run(steps, time_kernels=True)
+        fab.fence(raw)
+        regions.append(time.perf_counter() - t0)
+        ms = eng.collect()
+        kernel_ms += ms["step"]
+        # overlapped: device time of the region's last exchange on the side stream; in line: HIP-event laps around it
+        gather_ms += (raw.gather_wait(host=True) * gt if gt else 0.0) if loop.overlap else ms["gather"]
+        launches += ln
+        gathers += gt
+    regions = fab.max_over_ranks(regions)                       # a region takes as long as its slowest rank
+    # sanity on what was computed (not timed): returns are small integers, every rank's shard arrived
+    tr = raw.total_reward()
+    assert np.isfinite(tr).all() and np.all(tr == np.round(tr))
+    assert loop.gathered is not None and loop.gathered.numel() == n_total
+    g = loop.gathered.cpu().numpy()
+    assert np.all(g == np.round(g)) and np.abs(g).max() <= L    # returns of an L-step episode
+    elapsed = float(np.median(regions))
+    return {"elapsed": elapsed, "ms_per_step": elapsed / steps * 1e3, "ms_per_step_min": float(regions.min()) / steps * 1e3,
+            "ms_per_step_max": float(regions.max()) / steps * 1e3, "step_us": kernel_ms * 1e3 / max(1, launches),
+            "launches": launches, "gather_us": gather_ms * 1e3 / max(1, gathers), "gathers_per_region": gathers // reps,
+            "repeats": reps, "prewarm": prewarm, "episode_len": L, "value": n_total * steps / elapsed}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -312,7 +443,8 @@ def main():
     ap.add_argument("--envs-per-gpu", type=int, default=1048576, help="weak scaling (default): arms owned by every GPU")
     ap.add_argument("--envs-total", type=int, default=0,
                     help="strong scaling: total arms, sharded over the GPUs (--gpus 8 --envs-total 4194304 = "
-                         "BASELINE.json configs[3]; --envs-total 1048576 = the north-star curve)")
+                         "BASELINE.json configs[3]; --envs-total 1048576 = the north-star curve).  With N > 1 both are "
+                         "also run as secondary legs of the default (weak) invocation")
     ap.add_argument("--dof", type=int, default=4, choices=(4, 7))
     ap.add_argument("--targets", type=int, default=7)
     ap.add_argument("--episode-len", type=int, default=50)       # test_multi.py:8
@@ -375,130 +507,107 @@ def main():
         else:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             dist.init_process_group(backend="gloo", rank=rank, world_size=world)
-
-    strong = args.envs_total > 0
-    if strong:
-        n_total = args.envs_total
-        base, n_local = D.shard_range(n_total, rank, world)
-    else:
-        n_local = args.envs_per_gpu
-        n_total = n_local * world                               # weak scaling: per-GPU work fixed
-        base = rank * n_local
-    table = m.REF_DH_TABLE if args.dof == 4 else m.DH7_TABLE
-    radius = 51.3 if args.dof == 4 else 92.6
-    raw = m.StepEngine(n_local, args.targets, dh_table=table, radius=radius, device=dev, env_id_base=base,
-                       hw_trig=args.hw_trig, dh_in_lds=args.dh_in_lds, direct_trig=args.direct_trig,
-                       specialize=not args.no_specialize, ablate=args.ablate)
-    # The engine keeps its own stream: step launches, the RCCL gather and the resets are all enqueued on it through the
-    # C ABI, in program order; torch only brackets the timed regions (barrier + torch.cuda.synchronize()).
-    gather_fallback = None
-    if world > 1 and not args.rehearsal:
-        err = None
-        try:
-            D.connect(raw, rank, world)                         # mt_comm_unique_id -> store -> mt_comm_init (RCCL)
-        except Exception as e:                                  # noqa: BLE001 -- reported below, on every rank
-            err = e
-        # Contingency (never taken where mt_comm_init works): if ANY rank could not join the communicator, all ranks
-        # drop it and gather through the torch.distributed process group instead, and the JSON line says so.
-        flag = torch.tensor([1 if err is not None else 0], dtype=torch.int32,
-                            device="cuda" if backend == "nccl" else "cpu")
-        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-        if int(flag.item()):
-            print(f"[bench] rank {rank}: mt_comm_init path unavailable ({err}); gathering through torch.distributed "
-                  f"({backend}) instead", file=sys.stderr)
-            if err is None:
-                raw.comm_destroy()
-            if backend == "nccl":
-                D.attach_torch_gather(raw, n_total, rank, world)
-            else:
-                D.attach_gloo_gather(raw, n_total, rank, world)
-            gather_fallback = f"mt_comm_init failed on at least one rank ({err if err is not None else 'another rank'})"
-    elif world > 1:
-        D.attach_gloo_gather(raw, n_total, rank, world)         # rehearsal stand-in for the RCCL gather
-    eng = TimedEngine(raw)
-    L = max(1, min(args.episode_len, args.steps))               # >= 1 gather inside every timed region
-    loop = EpisodeLoop(eng, args.seed, L, fused=args.fused, overlap=not args.sync_gather)
-
+    ctrl_dev = "cuda" if backend == "nccl" else "cpu"
     # Barrier of the timed regions at N > 1: a shared-memory barrier between the ranks of the node (microseconds); the
     # process group's collective barrier (tens of microseconds inside a 0.9 ms region) only if that cannot be set up.
     host_barrier = D.make_host_barrier(rank, world) if world > 1 else None
+    fab = Fabric(rank, world, dist if world > 1 else None, torch, ctrl_dev, host_barrier, torch.cuda.synchronize)
 
-    def fence():
-        if world > 1:
-            # drain this rank's own queues first (incl. an exchange still running on the engine's side stream): the
-            # barrier is then passed only when every rank's device work is complete, and a collective barrier never
-            # shares the device with an exchange of the other communicator
-            raw.sync()
-            if host_barrier is not None:
-                host_barrier.wait()
-            else:
-                dist.barrier()
-        torch.cuda.synchronize()
+    table = m.REF_DH_TABLE if args.dof == 4 else m.DH7_TABLE
+    radius = 51.3 if args.dof == 4 else 92.6
+    bpe = algorithmic_bytes_per_env_step(args.dof, args.targets)
+    bpe_actual = actual_bytes_per_env_step(args.dof, args.targets)
 
-    # ---- pre-warm: >= PREWARM_S of step launches, so that the timed regions run at the steady clock ------------
-    prewarm = 0
-    fence()
-    t0 = time.perf_counter()
-    ctrl_dev = "cuda" if backend == "nccl" else "cpu"
+    def make_engine(n_total, strong):
+        """This rank's shard of `n_total` envs (strong) or its own n_total / world (weak), with its gather attached:
+        mt_comm_init over RCCL, or -- agreed on by all ranks -- the stand-ins.  -> (engine, n_local, how the gather runs)."""
+        if strong:
+            base, n_local = D.shard_range(n_total, rank, world)
+        else:
+            n_local = n_total // world
+            base = rank * n_local
+        raw = m.StepEngine(n_local, args.targets, dh_table=table, radius=radius, device=dev, env_id_base=base,
+                           hw_trig=args.hw_trig, dh_in_lds=args.dh_in_lds, direct_trig=args.direct_trig,
+                           specialize=not args.no_specialize, ablate=args.ablate)
+        # The engine keeps its own stream: step launches, the RCCL gather and the resets are all enqueued on it through the
+        # C ABI, in program order; torch only brackets the timed regions (barrier + torch.cuda.synchronize()).
+        fallback = None
+        if world > 1 and not args.rehearsal:
+            err = None
+            try:
+                D.connect(raw, rank, world)                     # mt_comm_unique_id -> store -> mt_comm_init (RCCL)
+            except Exception as e:                              # noqa: BLE001 -- reported below, on every rank
+                err = e
+            # Contingency (never taken where mt_comm_init works): if ANY rank could not join the communicator, all ranks
+            # drop it and gather through the torch.distributed process group instead, and the JSON line says so.
+            if fab.any_rank(err is not None):
+                print(f"[bench] rank {rank}: mt_comm_init path unavailable ({err}); gathering through torch.distributed "
+                      f"({backend}) instead", file=sys.stderr)
+                if err is None:
+                    raw.comm_destroy()
+                if backend == "nccl":
+                    D.attach_torch_gather(raw, n_total, rank, world)
+                else:
+                    D.attach_gloo_gather(raw, n_total, rank, world)
+                fallback = f"mt_comm_init failed on at least one rank ({err if err is not None else 'another rank'})"
+        elif world > 1:
+            D.attach_gloo_gather(raw, n_total, rank, world)     # rehearsal stand-in for the RCCL gather
+        return raw, n_local, fallback
 
-    def rank0_says(flag):
-        """The pre-warm is time-based, but its chunks contain collectives (the gathers): every rank must run the same
-        number of them, so rank 0's clock decides for everybody."""
+    def describe_collective(fallback):
         if world == 1:
-            return flag
-        t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=ctrl_dev)
-        dist.broadcast(t, src=0)
-        return bool(int(t.item()))
+            return "none (1 GPU: mt_gather_returns is a device copy)"
+        if args.rehearsal:
+            return "gloo all-gather (REHEARSAL on one device, not RCCL)"
+        if fallback:
+            return f"FALLBACK: torch.distributed ({backend}) all-gather of the returns per episode, in line; {fallback}"
+        if os.environ.get("MT_RCCL_LIB", "").endswith("libfake_rccl.so"):
+            return ("mt_gather_returns (C ABI) over the shared-memory STAND-IN for librccl (tests/fake_rccl): a rehearsal of "
+                    "the N > 1 product path on one GPU, not a scaling number")
+        return "RCCL all-gather of returns per episode through mt_gather_returns (C ABI), straight from the arena"
 
-    while rank0_says(time.perf_counter() - t0 < PREWARM_S):
-        loop.run(max(L, 200))
-        prewarm += max(L, 200)
-        torch.cuda.synchronize()
-    est_s = (time.perf_counter() - t0) / prewarm * args.steps   # one region, estimated
-    if world > 1:
-        t = torch.tensor([est_s], dtype=torch.float64, device=ctrl_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        est_s = float(t.item())
-    repeats = args.repeats or int(min(100, max(5, math.ceil(MIN_TIMED_S / max(est_s, 1e-6)))))
-    loop.run(args.warmup)                                       # the W untimed warm-up steps of the contract
-    fence()
+    def gather_mode(fallback):
+        if fallback or args.rehearsal:
+            return "in line (the stand-in gathers do not overlap anything)"
+        return ("in line on the engine's stream" if args.sync_gather else
+                "overlapped: snapshot + exchange on the engine's side stream (mt_gather_returns_begin)")
 
-    # ---- timed: `repeats` regions of EXACTLY --steps steps, each bracketed by barrier + synchronize -----------
-    regions, kernel_ms, gather_ms, launches, gathers = [], 0.0, 0.0, 0, 0
-    for _ in range(repeats):
-        eng.start_region()
-        fence()
-        t0 = time.perf_counter()
-        ln, gt = loop.run(args.steps, time_kernels=True)
-        fence()
-        regions.append(time.perf_counter() - t0)
-        ms = eng.collect()
-        kernel_ms += ms["step"]
-        # overlapped: device time of the region's last exchange on the side stream; in line: HIP-event laps around it
-        gather_ms += (raw.gather_wait(host=True) * gt if gt else 0.0) if loop.overlap else ms["gather"]
-        launches += ln
-        gathers += gt
-    regions = np.array(regions)
-    if world > 1:
-        t = torch.tensor(regions, dtype=torch.float64, device=ctrl_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)                # a region takes as long as its slowest rank
-        regions = t.cpu().numpy()
-    elapsed = float(np.median(regions))
+    def secondary_leg(n_total, fused, label):
+        """A further (strong-scaling) configuration on the same ranks: fresh engines + their own communicator, the same
+        episode loop, real gather and fences as the headline; shorter pre-warm."""
+        raw, n_local, fallback = make_engine(n_total, True)
+        r = measure(fab, raw, n_total, args.steps, args.warmup, args.episode_len, args.seed, fused=fused,
+                    overlap=not args.sync_gather, prewarm_s=0.15, min_timed_s=0.03)
+        name = "rollout_kernel (fused, one launch per episode segment)" if fused else raw.step_kernel_name()
+        raw.close()
+        out = {"what": label, "scaling": "strong", "envs_total": n_total, "envs_on_rank0": n_local, "n_gpus": world,
+               "value": r["value"], "unit": "env-steps/s", "ms_per_step": r["ms_per_step"],
+               "ms_per_step_min": r["ms_per_step_min"], "ms_per_step_max": r["ms_per_step_max"],
+               "avg_kernel_us": r["step_us"], "kernel": name, "gather_us": r["gather_us"],
+               "gathers_in_timed_region": r["gathers_per_region"], "repeats": r["repeats"], "episode_len": r["episode_len"],
+               "collective": describe_collective(fallback), "gather_mode": gather_mode(fallback)}
+        if not fused:                                           # per-GPU fraction of the HBM peak while a step is on the device
+            out["frac_of_hbm_peak_per_gpu"] = bpe_actual * n_local / (r["step_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS
+            out["bytes_per_env_step"] = bpe_actual
+        return out
 
-    # sanity on what was computed (not timed): returns are small integers, something happened
-    tr = raw.total_reward()
-    assert np.isfinite(tr).all() and np.all(tr == np.round(tr))
+    # ---- the headline: weak scaling (per-GPU work fixed) unless --envs-total ------------------------------------
+    strong = args.envs_total > 0
+    n_total = args.envs_total if strong else args.envs_per_gpu * world
+    raw, n_local, gather_fallback = make_engine(n_total, strong)
+    r = measure(fab, raw, n_total, args.steps, args.warmup, args.episode_len, args.seed, fused=args.fused,
+                overlap=not args.sync_gather, repeats=args.repeats)
     if args.ablate:
         print("ABLATION BUILD: timings only, outputs are not the reference's", file=sys.stderr)
-    assert loop.gathered is not None and loop.gathered.numel() == n_total
-    g = loop.gathered.cpu().numpy()
-    assert np.all(g == np.round(g)) and np.abs(g).max() <= L    # every rank's shard arrived: returns of an L-step episode
+    L = r["episode_len"]
+    kernel_name = raw.step_kernel_name()
+    raw.close()
 
+    out = None
     if rank == 0:
-        bpe = algorithmic_bytes_per_env_step(args.dof, args.targets)
-        bpe_actual = actual_bytes_per_env_step(args.dof, args.targets)
-        avg_kernel_s = kernel_ms / launches / 1e3
-        achieved = bpe * n_local / avg_kernel_s / 1e9
+        step_s = r["step_us"] * 1e-6                            # device time of one step of this rank's envs (HIP events)
+        achieved = bpe_actual * n_local / step_s / 1e9
+        achieved_model = bpe * n_local / step_s / 1e9
         trig = 2 if args.hw_trig else (1 if args.direct_trig else 0)
         static = not (args.no_specialize or args.dh_in_lds)
         table_name = ("Ref4Table" if args.dof == 4 else "Dh7Table") if static else f"RtTable<{args.dof}>"
@@ -507,36 +616,24 @@ def main():
                                            ("dh_in_lds", args.dh_in_lds)) if on)
         workload = f"{n_local} arms/GPU x {world} GPU, {args.dof}-DoF DH chain, K={args.targets} targets, " \
                    f"25 sub-steps, random integer-degree actions drawn in-kernel, episode {L} steps"
-        collective = "none (1 GPU: mt_gather_returns is a device copy)"
-        if world > 1:
-            collective = ("gloo all-gather (REHEARSAL on one device, not RCCL)" if args.rehearsal else
-                          "RCCL all-gather of returns per episode through mt_gather_returns (C ABI), straight from the arena")
-            if gather_fallback:
-                collective = f"FALLBACK: torch.distributed ({backend}) all-gather of the returns per episode, in line; " \
-                             f"{gather_fallback}"
-            elif os.environ.get("MT_RCCL_LIB", "").endswith("libfake_rccl.so"):
-                collective = "mt_gather_returns (C ABI) over the shared-memory STAND-IN for librccl (tests/fake_rccl): " \
-                             "a rehearsal of the N > 1 product path on one GPU, not a scaling number"
+        working_set_mb = bpe_actual * n_local / 1e6
         out = {
-            "metric": METRIC, "value": n_total * args.steps / elapsed, "unit": "env-steps/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "metric": METRIC, "value": r["value"], "unit": "env-steps/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": r["ms_per_step"],
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": workload, "envs_per_gpu": n_local, "envs_total": n_total, "dof": args.dof,
-                       "targets": args.targets, "substeps": 25, "episode_len": L, "collective": collective,
-                       "kernel_variant": variant, "prewarm_launches": prewarm, "repeats": repeats,
-                       "gathers_in_timed_region": gathers // repeats,
-                       "gather_mode": "in line on the engine's stream" if args.sync_gather else
-                                      "overlapped: snapshot + exchange on the engine's side stream (mt_gather_returns_begin)",
+                       "targets": args.targets, "substeps": 25, "episode_len": L, "collective": describe_collective(gather_fallback),
+                       "kernel_variant": variant, "prewarm_launches": r["prewarm"], "repeats": r["repeats"],
+                       "gathers_in_timed_region": r["gathers_per_region"], "gather_mode": gather_mode(gather_fallback),
                        "timing": "median over `repeats` regions of exactly `steps` steps, each bracketed by barrier + "
                                  "torch.cuda.synchronize(), max over ranks",
                        "barrier": "none (one rank)" if world == 1 else
                                   ("device drained, then a shared-memory barrier between the node's ranks "
                                    "(manytor_amd.distributed.HostBarrier)" if host_barrier is not None else
                                    "device drained, then torch.distributed barrier")},
-            "ms_per_step_min": float(regions.min()) / args.steps * 1e3,
-            "ms_per_step_max": float(regions.max()) / args.steps * 1e3,
-            "gather_us": gather_ms * 1e3 / max(1, gathers),
+            "ms_per_step_min": r["ms_per_step_min"], "ms_per_step_max": r["ms_per_step_max"],
+            "gather_us": r["gather_us"],
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
@@ -544,57 +641,78 @@ def main():
                 "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, committed under "
                                   "profiles/ (traffic.json); not re-measured in this run",
                 "kernel": (f"rollout_kernel<{table_name}> ({L} steps per launch; us per step quoted)" if args.fused else
-                           raw.step_kernel_name() + " (action drawn in-kernel)"),
-                "bytes_per_env_step": bpe, "avg_kernel_us": avg_kernel_s * 1e6, "kernel_launches_timed": launches,
-                "bytes_per_env_step_actual": bpe_actual,
-                "achieved_actual": bpe_actual * n_local / avg_kernel_s / 1e9,
-                "frac_actual": bpe_actual * n_local / avg_kernel_s / 1e9 / HBM_PEAK_GBS,
-                "note": "bytes_per_env_step = SURVEY 8(d) model (counts a 4D-byte action read); the timed kernel draws "
-                        "the action in registers, so *_actual (model - 4D) is what it moves.  At 1 048 576 arms the "
-                        "244 MB working set is about the size of the 256 MiB Infinity Cache: the pure-HBM point is "
-                        "secondary.other_configs['4194304 arms']",
+                           kernel_name + " (action drawn in-kernel)"),
+                "bytes_per_env_step": bpe_actual, "avg_kernel_us": r["step_us"], "kernel_launches_timed": r["launches"],
+                "bytes_per_env_step_survey_model": bpe, "achieved_survey_model": achieved_model,
+                "frac_survey_model": achieved_model / HBM_PEAK_GBS,
+                "regime": ("HBM + Infinity Cache: the %.0f MB a step touches are about the size of the 256 MiB MALL, so part "
+                           "of the re-read state is served on-die; the pure-HBM point is secondary.other_configs['4194304 "
+                           "arms ...']" % working_set_mb) if working_set_mb < 400 else "HBM (working set beyond the Infinity Cache)",
+                "note": "achieved / frac use the bytes the timed kernel really moves per env-step (SURVEY 8(d)'s 12 D + 24 K + "
+                        "33 minus the 4 D-byte action read it does not do: the action is drawn in registers and IS the new "
+                        "goals); *_survey_model are the same with SURVEY's own figure.  avg_kernel_us = device time of ONE "
+                        "STEP of this rank's envs by HIP events around the step launches; when mt_rollout runs the step as "
+                        "two concurrent launches on two streams (config.kernel says so) rocprofv3's per-launch average is "
+                        "about twice this divided by the overlap -- profiles/ holds the per-step union from the same trace",
             },
         }
         if world == 1:
-            copy_gbs = measured_copy_bandwidth(torch)
-            out["roofline"]["measured_copy_gbs"] = copy_gbs
-            out["roofline"]["frac_actual_of_measured_copy"] = out["roofline"]["achieved_actual"] / copy_gbs
-        secondary = world == 1 and not args.fused and not args.ablate and not args.no_secondary
-        if secondary:
-            # informational, not the headline: the same episodes as ONE launch each
-            us, _ = time_step_launches(m, n_local, table, radius, args.targets, dev, args.seed, fused=True, steps=1000)
-            out["secondary"] = {"fused_rollout": {
-                "env_steps_per_s": n_local / (us * 1e-6), "us_per_step": us, "steps_per_launch": 50,
-                "note": "mt_rollout_fused: state stays in registers/LDS between steps, bit-identical results; "
-                        "arithmetic-bound, so the per-step byte model does not apply"}}
-            us, us_sample = time_loaded_action_steps(m, n_local, table, radius, args.targets, dev, args.seed)
-            out["secondary"]["loaded_action_step"] = {
-                "us_per_step": us, "sample_actions_us": us_sample,
-                "env_steps_per_s": n_local / (us * 1e-6), "bytes_per_env_step": bpe,
-                "frac_of_hbm_peak": bpe * n_local / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                "note": "mt_step with the actions read from HBM (policy-in-the-loop shape, step_kernel<SAMPLE = false>): "
-                        "the kernel that moves exactly the SURVEY 8(d) bytes; the actions are written by a separate "
-                        "mt_sample_actions launch whose own time (sample_actions_us) is subtracted"}
-            # BASELINE.json's other single-GPU configurations and the pure-HBM point, same kernel path, short runs
-            out["secondary"]["other_configs"] = {}
-            for label, n2, tbl, rad in (("configs[1]: 65536 arms, 4-DoF", 65536, m.REF_DH_TABLE, 51.3),
-                                        ("131072 arms, 4-DoF (1 M arms over 8 GPUs, per-GPU shard)", 131072, m.REF_DH_TABLE, 51.3),
-                                        ("4194304 arms, 4-DoF (1 GB working set: pure HBM regime)", 4194304, m.REF_DH_TABLE, 51.3),
-                                        ("configs[4]: 1048576 arms, 7-DoF table", 1048576, m.DH7_TABLE, 92.6)):
-                us, kname = time_step_launches(m, n2, tbl, rad, args.targets, dev, args.seed,
-                                               steps=300 if n2 > (1 << 21) else 600)
-                b2 = algorithmic_bytes_per_env_step(len(tbl), args.targets)
-                b2a = actual_bytes_per_env_step(len(tbl), args.targets)
-                out["secondary"]["other_configs"][label] = {
-                    "us_per_step": us, "kernel": kname, "env_steps_per_s": n2 / (us * 1e-6), "bytes_per_env_step": b2,
-                    "frac_of_hbm_peak": b2 * n2 / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                    "bytes_per_env_step_actual": b2a,
-                    "frac_actual_of_hbm_peak": b2a * n2 / (us * 1e-6) / 1e9 / HBM_PEAK_GBS}
+            out["roofline"]["measured_copy_gbs"] = measured_copy_bandwidth(torch)
+    secondary = world == 1 and not args.fused and not args.ablate and not args.no_secondary
+    if secondary and rank == 0:
+        # informational, not the headline: the same episodes as ONE launch each
+        us, _ = time_step_launches(m, n_local, table, radius, args.targets, dev, args.seed, fused=True, steps=1000)
+        out["secondary"] = {"fused_rollout": {
+            "env_steps_per_s": n_local / (us * 1e-6), "us_per_step": us, "steps_per_launch": 50,
+            "note": "mt_rollout_fused: state stays in registers/LDS between steps, bit-identical results; "
+                    "arithmetic-bound, so the per-step byte model does not apply"}}
+        us, us_sample = time_loaded_action_steps(m, n_local, table, radius, args.targets, dev, args.seed)
+        out["secondary"]["loaded_action_step"] = {
+            "us_per_step": us, "sample_actions_us": us_sample,
+            "env_steps_per_s": n_local / (us * 1e-6), "bytes_per_env_step": bpe,
+            "frac_of_hbm_peak": bpe * n_local / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+            "note": "mt_step with the actions read from HBM (policy-in-the-loop shape, step_kernel<SAMPLE = false>): "
+                    "the kernel that moves exactly the SURVEY 8(d) bytes; the actions are written by a separate "
+                    "mt_sample_actions launch whose own time (sample_actions_us) is subtracted"}
+        # BASELINE.json's other single-GPU configurations and the pure-HBM point, same kernel path, short runs
+        out["secondary"]["other_configs"] = {}
+        for label, n2, tbl, rad in (("configs[1]: 65536 arms, 4-DoF", 65536, m.REF_DH_TABLE, 51.3),
+                                    ("131072 arms, 4-DoF (1 M arms over 8 GPUs, per-GPU shard)", 131072, m.REF_DH_TABLE, 51.3),
+                                    ("4194304 arms, 4-DoF (1 GB working set: pure HBM regime)", 4194304, m.REF_DH_TABLE, 51.3),
+                                    ("configs[4]: 1048576 arms, 7-DoF table", 1048576, m.DH7_TABLE, 92.6)):
+            us, kname = time_step_launches(m, n2, tbl, rad, args.targets, dev, args.seed,
+                                           steps=300 if n2 > (1 << 21) else 600)
+            b2 = algorithmic_bytes_per_env_step(len(tbl), args.targets)
+            b2a = actual_bytes_per_env_step(len(tbl), args.targets)
+            out["secondary"]["other_configs"][label] = {
+                "us_per_step": us, "kernel": kname, "env_steps_per_s": n2 / (us * 1e-6),
+                "bytes_per_env_step": b2a, "frac_of_hbm_peak": b2a * n2 / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                "bytes_per_env_step_survey_model": b2,
+                "frac_survey_model": b2 * n2 / (us * 1e-6) / 1e9 / HBM_PEAK_GBS}
+    if world > 1 and not args.fused and not args.ablate and not args.no_secondary:
+        # One N > 1 invocation yields every figure BASELINE.json's north_star names: next to the (weak) headline, the
+        # 1 M-arm job and configs[3] (4 194 304 arms) SHARDED over these ranks, per-step launches and fused segments.
+        # Collective code: every rank runs every leg.
+        legs = {}
+        for key, nt, label in (("strong_1m", 1048576, "north_star: 1 048 576 arms sharded over the GPUs (the 1 -> N curve)"),
+                               ("config3", 4194304, "BASELINE.json configs[3]: 4 194 304 arms sharded over the GPUs")):
+            if strong and nt == n_total:
+                continue                                        # that IS the headline of this invocation
+            leg = secondary_leg(nt, False, label)
+            f = secondary_leg(nt, True, label + ", mt_rollout_fused segments")
+            leg["fused"] = {k_: f[k_] for k_ in ("value", "ms_per_step", "avg_kernel_us", "gather_us", "gathers_in_timed_region",
+                                                 "kernel", "repeats")}
+            leg["fused_us_per_step"] = f["avg_kernel_us"]
+            legs[key] = leg
+        if rank == 0:
+            out["secondary"] = legs
+            out["secondary"]["note"] = ("`value` of the JSON line is the weak-scaling headline (scaling = weak: per-GPU work "
+                                        "fixed); each leg here states its own scaling")
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(table, args.targets)
         os.write(json_fd, (json.dumps(out) + "\n").encode())
 
-    raw.close()
     if host_barrier is not None:
         host_barrier.close()
     if world > 1:

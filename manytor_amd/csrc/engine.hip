@@ -5,6 +5,7 @@
 // computes in manytor.py:17-53,141-260 runs in the kernels of kernels.h.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -90,8 +91,10 @@ int match_static(const DhConst& t, int dof) {
   return 0;
 }
 
+// whole_rows: the launch covers the batch or a 256-aligned range of it (not the single-env view), so threads past the
+// end of the range may read on to the end of their block inside the rows (what the TT kernels do before their barrier)
 template <class Tbl, bool LDS_OK>
-void launch_step_t(mt_handle h, const StepArgs& args, bool sample) {
+void launch_step_t(mt_handle h, const StepArgs& args, bool sample, bool whole_rows) {
   const dim3 g = grid_for(args.n), b(kBlock);
 #define MT_LAUNCH_STEP(SAMPLE_, TRIG_, LDS_) \
   hipLaunchKernelGGL((step_kernel<Tbl, SAMPLE_, TRIG_, LDS_>), g, b, 0, h->stream, args)
@@ -101,9 +104,21 @@ void launch_step_t(mt_handle h, const StepArgs& args, bool sample) {
     }
     return;
   }
+  // sampled actions of a compile-time table on the whole batch: both end poses' sines / cosines from the table (TT)
+  bool tt = false;
+  if constexpr (ActionTrigTable<Tbl>::value) tt = sample && h->trig == 0 && h->trig_steps && whole_rows;
   if (h->trig == 0 && h->split) {  // tiny batches: one env over 2 or 4 lanes (kernels.h, step_split_kernel)
     const int64_t per_block = kBlock / h->split;
     const dim3 gs((unsigned)((args.n + per_block - 1) / per_block));
+    if constexpr (ActionTrigTable<Tbl>::value) {
+      if (tt) {
+        if (h->split == 2)
+          hipLaunchKernelGGL((step_split_kernel<Tbl, true, 2, true>), gs, b, 0, h->stream, args);
+        else
+          hipLaunchKernelGGL((step_split_kernel<Tbl, true, 4, true>), gs, b, 0, h->stream, args);
+        return;
+      }
+    }
     if (h->split == 2) {
       if (sample)
         hipLaunchKernelGGL((step_split_kernel<Tbl, true, 2>), gs, b, 0, h->stream, args);
@@ -116,6 +131,15 @@ void launch_step_t(mt_handle h, const StepArgs& args, bool sample) {
         hipLaunchKernelGGL((step_split_kernel<Tbl, false, 4>), gs, b, 0, h->stream, args);
     }
     return;
+  }
+  if constexpr (ActionTrigTable<Tbl>::value) {
+    if (tt) {
+      if (h->prefetch)
+        hipLaunchKernelGGL((step_kernel<Tbl, true, 0, false, kPrefetch, true>), g, b, 0, h->stream, args);
+      else
+        hipLaunchKernelGGL((step_kernel<Tbl, true, 0, false, 0, true>), g, b, 0, h->stream, args);
+      return;
+    }
   }
   if (h->trig == 0 && h->prefetch) {  // small batches: target loads in flight before the kinematics (kernels.h, PF)
     if (sample)
@@ -136,8 +160,8 @@ void launch_step_t(mt_handle h, const StepArgs& args, bool sample) {
 }
 
 template <int D>
-void launch_step_d(mt_handle h, const StepArgs& args, bool sample) {
-  launch_step_t<RtTable<D>, true>(h, args, sample);
+void launch_step_d(mt_handle h, const StepArgs& args, bool sample, bool whole_rows) {
+  launch_step_t<RtTable<D>, true>(h, args, sample, whole_rows);
 }
 
 template <int D>
@@ -178,18 +202,80 @@ void launch_step_frames_d(mt_handle h, const StepArgs& args, bool sample) {
 
 // One env step of the envs `args` describes (the whole batch, or one env of it: args_for_env); `trace` is the
 // matching view of the sub-step trace buffer or NULL.
-void launch_step(mt_handle h, const StepArgs& args, float* trace, bool sample) {
+void launch_step(mt_handle h, const StepArgs& args, float* trace, bool sample, bool whole_rows) {
   if (trace) MT_DISPATCH_D(h->D, launch_trace_d, h, args, trace, sample);  // first: it needs the previous pose
   if (h->custom_frames) {
     MT_DISPATCH_D(h->D, launch_step_frames_d, h, args, sample);
     return;
   }
-  if (h->static_kind == 1) return launch_step_t<Ref4Table, false>(h, args, sample);
-  if (h->static_kind == 2) return launch_step_t<Dh7Table, false>(h, args, sample);
-  MT_DISPATCH_D(h->D, launch_step_d, h, args, sample);
+  if (h->static_kind == 1) return launch_step_t<Ref4Table, false>(h, args, sample, whole_rows);
+  if (h->static_kind == 2) return launch_step_t<Dh7Table, false>(h, args, sample, whole_rows);
+  MT_DISPATCH_D(h->D, launch_step_d, h, args, sample, whole_rows);
 }
 
-void launch_step(mt_handle h, bool sample) { launch_step(h, h->args, h->trace, sample); }
+void launch_step(mt_handle h, bool sample) { launch_step(h, h->args, h->trace, sample, true); }
+
+// ---- multi-chain rollouts ------------------------------------------------------------------------------------------
+StepArgs args_for_range(mt_handle h, const StepArgs& base, int64_t off, int64_t cnt);
+int check_launch(mt_handle h, const char* what);
+// Envs per chain: equal shares rounded up to whole 256-env blocks; the last chain takes what is left (possibly less).
+int64_t chain_span(mt_handle h, int chains) {
+  const int64_t per = (h->n + chains - 1) / chains;
+  return (per + 255) / 256 * 256;
+}
+
+int ensure_chains(mt_handle h, int chains) {
+  if (!h->ev_fork) MT_HIP(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+  for (int c = 1; c < chains; ++c) {
+    if (!h->chain_streams[c]) MT_HIP(h, hipStreamCreateWithFlags(&h->chain_streams[c], hipStreamNonBlocking));
+    if (!h->ev_join[c]) MT_HIP(h, hipEventCreateWithFlags(&h->ev_join[c], hipEventDisableTiming));
+  }
+  return MT_OK;
+}
+
+// One chain's T sampled steps on the handle's CURRENT stream (h->stream): chain c owns envs [c * span, (c + 1) * span).  The
+// step-kernel schedule is the one for the chain's env count (a chain is a batch of `span` envs).  `a0` carries seed /
+// major_base; step s is launched with major = major0 + s.
+void launch_chain(mt_handle h, const StepArgs& a0, uint32_t major0, int T, int chains, int c) {
+  const int64_t span = chain_span(h, chains), off = (int64_t)c * span;
+  if (off >= h->n) return;
+  StepArgs as = args_for_range(h, a0, off, std::min(span, h->n - off));
+  const int keep_split = h->split;
+  const bool keep_pf = h->prefetch;
+  h->split = h->chain_split;
+  h->prefetch = h->chain_prefetch;
+  for (int s = 0; s < T; ++s) {
+    as.major = major0 + (uint32_t)s;
+    launch_step(h, as, nullptr, true, true);
+  }
+  h->split = keep_split;
+  h->prefetch = keep_pf;
+}
+
+// Fork the chain streams from `root` (the stream the handle's work is ordered on), run body(c) with h->stream = chain
+// c's stream (chain 0: root itself), join them back into `root`.
+template <class Body>
+int fork_join_chains(mt_handle h, hipStream_t root, int chains, Body&& body) {
+  int rc = ensure_chains(h, chains);
+  if (rc) return rc;
+  const int64_t span = chain_span(h, chains);
+  MT_HIP(h, hipEventRecord(h->ev_fork, root));
+  for (int c = 1; c < chains; ++c)
+    if ((int64_t)c * span < h->n) MT_HIP(h, hipStreamWaitEvent(h->chain_streams[c], h->ev_fork, 0));
+  hipStream_t keep = h->stream;
+  for (int c = 0; c < chains && rc == MT_OK; ++c) {
+    if ((int64_t)c * span >= h->n) continue;
+    h->stream = c == 0 ? root : h->chain_streams[c];
+    rc = body(c);
+  }
+  h->stream = keep;
+  for (int c = 1; c < chains; ++c) {  // join even after a failure: nothing is left dangling off the root stream
+    if ((int64_t)c * span >= h->n) continue;
+    MT_HIP(h, hipEventRecord(h->ev_join[c], h->chain_streams[c]));
+    MT_HIP(h, hipStreamWaitEvent(root, h->ev_join[c], 0));
+  }
+  return rc;
+}
 
 // The view of ONE env of the batch: every row base moved `env` elements to the right, n = 1.  The wavefront ballot
 // of such a launch goes to a spare word; the real done_bits word is rebuilt afterwards (done_bits_word_kernel).
@@ -211,6 +297,29 @@ StepArgs args_for_env(mt_handle h, int64_t env) {
   if (a.zmin) a.zmin += env;
   a.n = 1;
   a.env_base += env;
+  return a;
+}
+
+// The view of a contiguous RANGE of envs [off, off + cnt) of the batch, off a multiple of 256 (whole blocks, whole ballot
+// words, 1 KiB-aligned row segments): what one chain of a multi-chain mt_rollout launches on.
+StepArgs args_for_range(mt_handle h, const StepArgs& base, int64_t off, int64_t cnt) {
+  StepArgs a = base;
+  a.actions += off;
+  a.goals += off;
+  a.points += off;
+  a.alive += off;
+  a.total_reward += off;
+  a.obs += off;
+  a.reward += off;
+  a.done += off;
+  a.done_bits += off / 64;
+  a.ee += off;
+  a.episodes += off;
+  a.last_return += off;
+  if (a.ring) a.ring += off;
+  if (a.zmin) a.zmin += off;
+  a.n = cnt;
+  a.env_base += off;
   return a;
 }
 
@@ -440,6 +549,13 @@ int mt_create(mt_handle* out, const mt_config* cfg) {
   h->reset_split = cfg->n_envs <= 65536;
   if (const char* env = std::getenv("MT_RESET_SPLIT")) h->reset_split = std::atoi(env) != 0;
   if (const char* env = std::getenv("MT_GRAPH")) h->graph_mode = std::atoi(env) != 0 ? 1 : 0;
+  // mt_rollout as independent chains of launches on separate streams (engine_internal.h): MT_CHAINS = 1..4 overrides
+  // Two chains from 196 608 to 3 M envs (tools/chain_sweep.py --steady, profiles/r03_variants.md section 2: 10.5 -> 8.7 us per
+  // step at 262 144 envs, 21.5 -> 19.8 at 524 288, 39.9 -> 36.3 at 1 M, 74.6 -> 69.0 at 2 M; nothing at 4 M, where the
+  // launches are long and purely HBM-bound; below, the fork / join of every call costs more than the overlap returns).
+  h->chains = (cfg->n_envs >= 196608 && cfg->n_envs <= 3145728) ? 2 : 1;
+  if (const char* env = std::getenv("MT_CHAINS")) h->chains = std::max(1, std::min((int)mt_engine::kMaxChains, std::atoi(env)));
+  if (cfg->n_envs < 2 * 256) h->chains = 1;
   h->prefetch_forced = false;
   if (const char* env = std::getenv("MT_PREFETCH")) {
     h->prefetch = std::atoi(env) != 0;
@@ -481,7 +597,7 @@ int mt_create(mt_handle* out, const mt_config* cfg) {
                o_done = take(ld), o_bits = take(ld / 64 * 8), o_ee = take(3 * ld * 4), o_epi = take(ld * 4),
                o_last = take(ld * 4), o_ring = take((size_t)cfg->return_ring * ld * 4), o_misc = take(256),
                o_trace = take((cfg->flags & MT_FLAG_TRACE) ? (size_t)cfg->substeps * 3 * ld * 4 : 0),
-               o_zmin = take((cfg->flags & MT_FLAG_DEBUG_ZMIN) ? ld * 4 : 0);
+               o_zmin = take((cfg->flags & MT_FLAG_DEBUG_ZMIN) ? ld * 4 : 0), o_trig = take(kTrigEntries * sizeof(SinCos));
   h->arena_bytes = off;
   if (hipMalloc(&h->arena, h->arena_bytes) != hipSuccess) {
     (void)hipGetLastError();
@@ -509,6 +625,9 @@ int mt_create(mt_handle* out, const mt_config* cfg) {
   h->spare_bits = (unsigned long long*)(base + o_misc + 64);  // ballot sink of single-env launches
   h->trace = (cfg->flags & MT_FLAG_TRACE) ? (float*)(base + o_trace) : nullptr;
   a.zmin = (cfg->flags & MT_FLAG_DEBUG_ZMIN) ? (float*)(base + o_zmin) : nullptr;
+  a.trig_table = (const float*)(base + o_trig);
+  hipLaunchKernelGGL(fill_trig_table_kernel, dim3(1), dim3(kBlock), 0, h->stream, (float*)(base + o_trig));
+  MT_HIP_C(hipGetLastError());
   a.n = h->n;
   a.ld = h->ld;
   a.env_base = cfg->env_id_base;
@@ -516,7 +635,7 @@ int mt_create(mt_handle* out, const mt_config* cfg) {
   a.S = cfg->substeps;
   a.tol = cfg->pickup_tol;
   a.inv_sm1 = 1.0f / (float)(cfg->substeps - 1);
-  a.flags = cfg->flags;
+  a.flags = cfg->flags & ~kFlagWholeGoals;  // the internal bit is the host's to set (resets / sampled steps), never the caller's
   a.dh = make_dh(cfg->dh_table, h->D);
   a.dh.fo = (cfg->obs_frame + h->D) % h->D;
   a.dh.fe = (cfg->ee_frame + h->D) % h->D;
@@ -529,6 +648,29 @@ int mt_create(mt_handle* out, const mt_config* cfg) {
   }
   h->static_kind = ((cfg->flags & (MT_FLAG_NO_SPECIALIZE | MT_FLAG_DH_IN_LDS)) || h->custom_frames) ? 0 : match_static(a.dh, h->D);
   if (h->static_kind == 1 && !h->prefetch_forced) h->prefetch = true;
+  // End-pose sines / cosines from the whole-degree table (step kernels with TT; tools/variant_sweep.py,
+  // profiles/r03_variants.md): MT_TRIG_TABLE = 0/1 overrides.
+  h->trig_steps = h->static_kind != 0;
+  if (const char* env = std::getenv("MT_TRIG_TABLE")) h->trig_steps = std::atoi(env) != 0 && h->static_kind != 0;
+  // A chain of a multi-chain mt_rollout is a batch of chain_span() envs: its launches use the schedule for THAT size
+  // (same thresholds and overrides as the whole-batch choice above).
+  h->chain_split = h->split;
+  h->chain_prefetch = h->prefetch;
+  if (h->chains > 1) {
+    const int64_t span = chain_span(h, h->chains);
+    h->chain_split = span <= 32768 ? 4 : (span <= 65536 ? 2 : 0);
+    h->chain_prefetch = span <= 131072;
+    if (const char* env = std::getenv("MT_SPLIT")) {
+      const int v = std::atoi(env);
+      h->chain_split = (v == 2 || v == 4) ? v : 0;
+    }
+    if (h->prefetch_forced) h->chain_prefetch = h->prefetch;
+    if (h->custom_frames) {
+      h->chain_split = 0;
+      h->chain_prefetch = false;
+    }
+    if (h->static_kind == 1 && !h->prefetch_forced) h->chain_prefetch = true;
+  }
 #undef MT_HIP_C
   *out = h;
   return MT_OK;
@@ -540,7 +682,17 @@ int mt_destroy(mt_handle h) {
   (void)hipStreamSynchronize(h->stream);
   mt_gather_release(h);  // drains the side stream before the communicator goes
   mt_comm_release(h);
-  for (auto& g : h->graphs) (void)hipGraphExecDestroy(g.exec);
+  for (auto& g : h->graphs)
+    for (hipGraphExec_t x : g.exec)
+      if (x) (void)hipGraphExecDestroy(x);
+  for (int c = 1; c < mt_engine::kMaxChains; ++c) {
+    if (h->chain_streams[c]) {
+      (void)hipStreamSynchronize(h->chain_streams[c]);
+      (void)hipStreamDestroy(h->chain_streams[c]);
+    }
+    if (h->ev_join[c]) (void)hipEventDestroy(h->ev_join[c]);
+  }
+  if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   if (h->graph_step0) (void)hipFree(h->graph_step0);
   if (h->staging) (void)hipFree(h->staging);
   if (h->pinned) (void)hipHostFree(h->pinned);
@@ -558,10 +710,15 @@ const char* mt_step_kernel_name(mt_handle h) {
   const char* tbl = h->static_kind == 1 ? "Ref4Table" : (h->static_kind == 2 ? "Dh7Table" : nullptr);
   std::string table = tbl ? tbl : (h->custom_frames ? "RtTableF<" : "RtTable<") + std::to_string(h->D) + ">";
   if (h->trig == 0 && !h->lds_table && h->split)
-    h->kernel_name = "step_split_kernel<" + table + ", L=" + std::to_string(h->split) + ">";
+    h->kernel_name = "step_split_kernel<" + table + ", L=" + std::to_string(h->split) + (h->trig_steps ? ", tt=1>" : ">");
   else
     h->kernel_name = "step_kernel<" + table + ", trig=" + std::to_string(h->trig) + ", lds=" + (h->lds_table ? "true" : "false") +
-                     ", pf=" + ((h->trig == 0 && !h->lds_table && h->prefetch) ? std::to_string(kPrefetch) : std::string("0")) + ">";
+                     ", pf=" + ((h->trig == 0 && !h->lds_table && h->prefetch) ? std::to_string(kPrefetch) : std::string("0")) +
+                     ((h->trig == 0 && !h->lds_table && h->trig_steps) ? ", tt=1>" : ">");
+  if (h->chains > 1)  // what mt_rollout launches instead: the schedule for a chain's env count, on row views
+    h->kernel_name += " [mt_rollout: " + std::to_string(h->chains) + " chains of " + std::to_string(chain_span(h, h->chains)) +
+                      " envs, " + (h->trig == 0 && !h->lds_table && h->chain_split ? "L=" + std::to_string(h->chain_split)
+                                   : std::string(h->trig == 0 && !h->lds_table && h->chain_prefetch ? "pf=8" : "pf=0")) + "]";
   return h->kernel_name.c_str();
 }
 
@@ -624,6 +781,7 @@ int mt_reset(mt_handle h, const float* points, int layout, int is_device) {
   }
   h->args.major = 0;  // caller-supplied targets start episode 0 of every env
   h->args.episode0 = 0;
+  h->args.flags |= kFlagWholeGoals;  // every env is at the zero pose after this launch
   MT_DISPATCH_D(h->D, launch_reset_d, h, h->args, 0);
   int rc = check_launch(h, "reset_kernel");
   if (rc) return rc;
@@ -638,7 +796,10 @@ static int reset_random_impl(mt_handle h, uint64_t seed, uint32_t episode, int m
   h->args.seed_lo = (uint32_t)seed;
   h->args.seed_hi = (uint32_t)(seed >> 32);
   h->args.major = episode;
-  if (mode == 1) h->args.episode0 = episode;  // full reset: finished-episode counts restart from here
+  if (mode == 1) {
+    h->args.episode0 = episode;  // full reset: finished-episode counts restart from here
+    h->args.flags |= kFlagWholeGoals;  // every env is at the zero pose after this launch
+  }
   MT_DISPATCH_D(h->D, launch_reset_d, h, h->args, mode);
   int rc = check_launch(h, "reset_kernel");
   if (rc) return rc;
@@ -712,6 +873,7 @@ int mt_step(mt_handle h) {
   if (!h->is_reset) return fail(h, MT_ERR_STATE, "mt_step before mt_reset / mt_reset_random");
   MT_ON_DEVICE(h, h->cfg.device);
   launch_step(h, false);
+  h->args.flags &= ~kFlagWholeGoals;  // staged actions are anybody's floats
   return check_launch(h, "step_kernel");
 }
 
@@ -753,6 +915,7 @@ int mt_step_host(mt_handle h, const void* actions, int dtype, float* obs, int32_
     default: hipLaunchKernelGGL((env_major_to_soa<int64_t>), g, b, 0, h->stream, (const int64_t*)dp, h->D, h->n, h->args.actions, h->ld); break;
   }
   launch_step(h, false);
+  h->args.flags &= ~kFlagWholeGoals;
   hipLaunchKernelGGL((soa_to_env_major<float>), g, b, 0, h->stream, h->args.obs, h->ld, 3 * h->K, h->n, (float*)dp_out);
   rc = check_launch(h, "mt_step_host");
   if (rc) return rc;
@@ -794,7 +957,8 @@ int mt_env_step(mt_handle h, int64_t env, const float* action, float* obs, int32
   const size_t pitch = (size_t)h->ld * 4;
   // column `env` of the D action rows <- D host floats
   MT_HIP(h, hipMemcpy2DAsync(a.actions, pitch, action, 4, 4, (size_t)h->D, hipMemcpyHostToDevice, h->stream));
-  launch_step(h, a, h->trace ? h->trace + env : nullptr, false);
+  launch_step(h, a, h->trace ? h->trace + env : nullptr, false, false);
+  h->args.flags &= ~kFlagWholeGoals;
   int rc = check_launch(h, "step_kernel (one env)");
   if (rc) return rc;
   rc = rebuild_done_word(h, env);
@@ -852,7 +1016,8 @@ static bool rollout_uses_graph(mt_handle h, int n_steps) {
   return true;
 }
 
-static int rollout_graph(mt_handle h, int T, uint64_t seed, hipGraphExec_t* out) {
+// The cached graph(s) of a T-step segment: one graph per chain (chain c's T launches), to be replayed on chain c's stream.
+static int rollout_graph(mt_handle h, int T, uint64_t seed, int chains, const mt_engine::RolloutGraph** out) {
   if (!h->graph_step0) MT_HIP(h, hipMalloc(&h->graph_step0, sizeof(uint32_t)));
   StepArgs a = h->args;
   a.seed_lo = (uint32_t)seed;
@@ -861,38 +1026,58 @@ static int rollout_graph(mt_handle h, int T, uint64_t seed, hipGraphExec_t* out)
   a.episode0 = 0;  // not read by the step kernels
   a.major_base = h->graph_step0;
   for (auto& g : h->graphs)
-    if (g.T == T && std::memcmp(&g.args, &a, sizeof a) == 0) {
-      *out = g.exec;
+    if (g.T == T && g.chains == chains && std::memcmp(&g.args, &a, sizeof a) == 0) {
+      *out = &g;
       return MT_OK;
     }
   // captured on the handle's private stream whatever stream the handle currently launches on (the caller's may be the
-  // null stream, which cannot capture); the instantiated graph is launched on the current one
-  hipGraph_t graph = nullptr;
+  // null stream, which cannot capture); the instantiated graphs are launched on the current one / the chain streams
+  mt_engine::RolloutGraph rg{};
+  rg.T = T;
+  rg.chains = chains;
+  rg.args = a;
   hipStream_t launch_stream = h->stream;
-  MT_HIP(h, hipStreamBeginCapture(h->own_stream, hipStreamCaptureModeThreadLocal));
-  h->stream = h->own_stream;
-  for (int s = 0; s < T; ++s) {
-    StepArgs as = a;
-    as.major = (uint32_t)s;
-    launch_step(h, as, nullptr, true);
+  auto drop = [&]() {
+    for (int c = 0; c < chains; ++c)
+      if (rg.exec[c]) (void)hipGraphExecDestroy(rg.exec[c]);
+  };
+  for (int c = 0; c < chains; ++c) {
+    if (c > 0 && (int64_t)c * chain_span(h, chains) >= h->n) break;
+    hipGraph_t graph = nullptr;
+    MT_HIP(h, hipStreamBeginCapture(h->own_stream, hipStreamCaptureModeThreadLocal));
+    h->stream = h->own_stream;
+    if (chains > 1) {
+      launch_chain(h, a, 0u, T, chains, c);
+    } else {
+      for (int s = 0; s < T; ++s) {
+        StepArgs as = a;
+        as.major = (uint32_t)s;
+        launch_step(h, as, nullptr, true, true);
+      }
+    }
+    h->stream = launch_stream;
+    hipError_t e = hipStreamEndCapture(h->own_stream, &graph);
+    if (e != hipSuccess || !graph) {
+      (void)hipGetLastError();
+      drop();
+      return fail(h, MT_ERR_HIP, std::string("mt_rollout: stream capture failed: ") + hipGetErrorString(e));
+    }
+    e = hipGraphInstantiate(&rg.exec[c], graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (e != hipSuccess) {
+      rg.exec[c] = nullptr;
+      drop();
+      return fail(h, MT_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
+    }
   }
-  h->stream = launch_stream;
-  hipError_t e = hipStreamEndCapture(h->own_stream, &graph);
-  if (e != hipSuccess || !graph) {
-    (void)hipGetLastError();
-    return fail(h, MT_ERR_HIP, std::string("mt_rollout: stream capture failed: ") + hipGetErrorString(e));
-  }
-  hipGraphExec_t exec = nullptr;
-  e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-  (void)hipGraphDestroy(graph);
-  if (e != hipSuccess) return fail(h, MT_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
   if (h->graphs.size() >= 8) {  // a handful of segment lengths at most; drop the oldest beyond that
     MT_HIP(h, hipStreamSynchronize(h->stream));
-    (void)hipGraphExecDestroy(h->graphs.front().exec);
+    for (hipGraphExec_t x : h->graphs.front().exec)
+      if (x) (void)hipGraphExecDestroy(x);
     h->graphs.erase(h->graphs.begin());
   }
-  h->graphs.push_back(mt_engine::RolloutGraph{T, a, exec});
-  *out = exec;
+  h->graphs.push_back(rg);
+  *out = &h->graphs.back();
   return MT_OK;
 }
 
@@ -900,36 +1085,79 @@ int mt_rollout(mt_handle h, int n_steps, uint64_t seed, uint32_t step_idx0) {
   MT_REQUIRE(nullptr, h != nullptr, "handle is NULL");
   MT_REQUIRE(h, n_steps >= 0, "n_steps must be >= 0");
   if (n_steps > 0 && !h->is_reset) return fail(h, MT_ERR_STATE, "mt_rollout before mt_reset / mt_reset_random");
-  if (n_steps > 0) {
-    MT_ON_DEVICE(h, h->cfg.device);
-    bool graph = rollout_uses_graph(h, n_steps);
-    if (graph && h->graph_mode < 0) {
-      // capture + instantiation cost about a dozen plain segments: only for a segment length that comes back
-      bool cached = false, seen = false;
-      for (auto& g : h->graphs) cached |= g.T == n_steps;
-      for (int t : h->graph_seen) seen |= t == n_steps;
-      if (!cached && !seen) {
-        if (h->graph_seen.size() >= 32) h->graph_seen.erase(h->graph_seen.begin());
-        h->graph_seen.push_back(n_steps);
-        graph = false;
-      }
-    }
-    if (graph) {
-      hipGraphExec_t exec = nullptr;
-      int rc = rollout_graph(h, n_steps, seed, &exec);
-      if (rc) return rc;
-      MT_HIP(h, hipMemsetD32Async((hipDeviceptr_t)h->graph_step0, (int)step_idx0, 1, h->stream));
-      MT_HIP(h, hipGraphLaunch(exec, h->stream));
-      h->args.seed_lo = (uint32_t)seed;
-      h->args.seed_hi = (uint32_t)(seed >> 32);
-      h->args.major = step_idx0 + (uint32_t)(n_steps - 1);
-      return MT_OK;
+  if (n_steps == 0) return MT_OK;
+  MT_ON_DEVICE(h, h->cfg.device);
+  // several independent chains of launches (env ranges on separate streams) where that pays; a caller who is capturing
+  // the handle's stream gets the plain single-stream sequence
+  int chains = (n_steps >= 2 && !h->trace) ? h->chains : 1;
+  if (chains > 1) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(h->stream, &st) != hipSuccess || st != hipStreamCaptureStatusNone) {
+      (void)hipGetLastError();
+      chains = 1;
     }
   }
-  for (int s = 0; s < n_steps; ++s) {
-    int rc = mt_step_random(h, seed, step_idx0 + (uint32_t)s);
+  bool graph = rollout_uses_graph(h, n_steps);
+  if (graph && h->graph_mode < 0) {
+    // capture + instantiation cost about a dozen plain segments: only for a segment length that comes back
+    bool cached = false, seen = false;
+    for (auto& g : h->graphs) cached |= g.T == n_steps;
+    for (int t : h->graph_seen) seen |= t == n_steps;
+    if (!cached && !seen) {
+      if (h->graph_seen.size() >= 32) h->graph_seen.erase(h->graph_seen.begin());
+      h->graph_seen.push_back(n_steps);
+      graph = false;
+    }
+  }
+  if (graph) {
+    const mt_engine::RolloutGraph* rg = nullptr;
+    int rc = rollout_graph(h, n_steps, seed, chains, &rg);
     if (rc) return rc;
+    MT_HIP(h, hipMemsetD32Async((hipDeviceptr_t)h->graph_step0, (int)step_idx0, 1, h->stream));
+    if (chains > 1) {
+      rc = fork_join_chains(h, h->stream, chains, [&](int c) -> int {
+        MT_HIP(h, hipGraphLaunch(rg->exec[c], h->stream));
+        return MT_OK;
+      });
+      if (rc) return rc;
+    } else {
+      MT_HIP(h, hipGraphLaunch(rg->exec[0], h->stream));
+    }
+  } else if (chains > 1) {
+    StepArgs a = h->args;
+    a.seed_lo = (uint32_t)seed;
+    a.seed_hi = (uint32_t)(seed >> 32);
+    // chains enqueued round-robin step by step, so that no stream runs dry while the host is busy with another one
+    int rc = ensure_chains(h, chains);
+    if (rc) return rc;
+    const int64_t span = chain_span(h, chains);
+    MT_HIP(h, hipEventRecord(h->ev_fork, h->stream));
+    for (int c = 1; c < chains; ++c)
+      if ((int64_t)c * span < h->n) MT_HIP(h, hipStreamWaitEvent(h->chain_streams[c], h->ev_fork, 0));
+    hipStream_t root = h->stream;
+    for (int st = 0; st < n_steps; ++st)
+      for (int c = 0; c < chains; ++c) {
+        h->stream = c == 0 ? root : h->chain_streams[c];
+        launch_chain(h, a, step_idx0 + (uint32_t)st, 1, chains, c);
+      }
+    h->stream = root;
+    rc = check_launch(h, "step_kernel (chained)");
+    for (int c = 1; c < chains; ++c) {
+      if ((int64_t)c * span >= h->n) continue;
+      MT_HIP(h, hipEventRecord(h->ev_join[c], h->chain_streams[c]));
+      MT_HIP(h, hipStreamWaitEvent(root, h->ev_join[c], 0));
+    }
+    if (rc) return rc;
+  } else {
+    for (int s = 0; s < n_steps; ++s) {
+      int rc = mt_step_random(h, seed, step_idx0 + (uint32_t)s);
+      if (rc) return rc;
+    }
+    return MT_OK;
   }
+  h->args.seed_lo = (uint32_t)seed;
+  h->args.seed_hi = (uint32_t)(seed >> 32);
+  h->args.major = step_idx0 + (uint32_t)(n_steps - 1);
   return MT_OK;
 }
 
@@ -1093,9 +1321,10 @@ int mt_set(mt_handle h, int field, const void* src, int64_t src_bytes) {
     int rc = ensure_staging(h, (size_t)need);
     if (rc) return rc;
     MT_HIP(h, hipMemcpyAsync(h->staging, src, (size_t)need, hipMemcpyHostToDevice, h->stream));
-    if (field == MT_F_GOALS)
+    if (field == MT_F_GOALS) {
       hipLaunchKernelGGL((env_major_to_soa<float>), g, b, 0, h->stream, (const float*)h->staging, h->D, h->n, a.goals, h->ld);
-    else if (field == MT_F_POINTS)
+      h->args.flags &= ~kFlagWholeGoals;
+    } else if (field == MT_F_POINTS)
       hipLaunchKernelGGL((env_major_to_soa<float>), g, b, 0, h->stream, (const float*)h->staging, 3 * h->K, h->n, a.points, h->ld);
     else if (field == MT_F_RETURN_RING)
       hipLaunchKernelGGL((env_major_to_soa<float>), g, b, 0, h->stream, (const float*)h->staging, (int)a.ring_slots, h->n, a.ring, h->ld);

@@ -11,6 +11,7 @@
 struct mt_comm;  // comm.hip: the RCCL communicator of a handle
 
 struct mt_engine {
+  static constexpr int kMaxChains = 4;  // mt_rollout's independent chains of launches (see `chains` below)
   mt_config cfg{};
   int64_t n = 0, ld = 0;
   int D = 0, K = 0;
@@ -36,6 +37,7 @@ struct mt_engine {
   int split = 0;          // step_split_kernel<..., L>: one env over L = 2 or 4 lanes (0 = one env per lane)
   bool prefetch_forced = false;
   bool prefetch = false;  // step_kernel<..., PF = kPrefetch>: target loads requested ahead of the kinematics
+  bool trig_steps = false;  // step kernels with TT: end-pose sines / cosines from the whole-degree table (static tables, sampled actions)
   int static_kind = 0;   // 0 runtime table, 1 Ref4Table, 2 Dh7Table
   mt_comm* comm = nullptr;
   // mt_gather_returns_begin / _wait: the exchange runs on a side stream from a snapshot of the row
@@ -48,13 +50,24 @@ struct mt_engine {
   // mt_rollout on small batches: the segment's launches are captured once into a HIP graph and replayed
   struct RolloutGraph {
     int T;
+    int chains;
     mt::StepArgs args;  // what the nodes were captured with (major = 0, episode0 = 0): any change rebuilds the graph
-    hipGraphExec_t exec;
+    hipGraphExec_t exec[kMaxChains];  // one graph per chain (a graph with parallel branches replays slower than
+                                      // independent graphs on independent streams: profiles/r03_variants.md)
   };
   std::vector<RolloutGraph> graphs;
   std::vector<int> graph_seen;      // segment lengths asked for once: a graph is built at the second request
   uint32_t* graph_step0 = nullptr;  // device word: first step index of the segment being replayed
   int graph_mode = -1;              // -1 by batch size, 0 never, 1 always (MT_GRAPH)
+  // mt_rollout as `chains` independent chains of launches (contiguous env ranges on separate streams): a step of env i
+  // depends only on env i's previous step, so while one range's kernel drains and its next one is dispatched the other
+  // ranges keep the chip busy (tools/multistream_probe.py, profiles/r03_variants.md).  Forked from and joined back to
+  // the handle's stream inside every mt_rollout call.
+  int chains = 1;
+  int chain_split = 0;          // the step-kernel schedule of a chain's launches is picked for the CHAIN's env count
+  bool chain_prefetch = false;
+  hipStream_t chain_streams[kMaxChains] = {nullptr, nullptr, nullptr, nullptr};  // [0] unused: chain 0 runs on `stream`
+  hipEvent_t ev_fork = nullptr, ev_join[kMaxChains] = {nullptr, nullptr, nullptr, nullptr};
   bool gather_pending = false;
   float last_gather_ms = 0.f;  // device time of the last exchange that was waited for (mt_gather_returns_wait / mt_sync)
   std::string err;

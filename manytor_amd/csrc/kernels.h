@@ -385,13 +385,28 @@ constexpr bool whole_degree_offsets() {
   }
   return true;
 }
-// all threads of the block, before anybody returns
-__device__ __forceinline__ void fill_action_trig(SinCos* trig) {
+// The table itself: sincos_deg of exactly the floats -270 .. 179, computed ONCE per handle by this kernel (mt_create) into
+// the arena.  Every block that wants it copies the 3 600 bytes into LDS (one 16-byte load per thread from L2, instead
+// of two range reductions + polynomials per thread and launch): the load is issued first, the write and the barrier
+// come after whatever the kernel can do in between (its pose loads, the Philox block).
+constexpr int kTrigVec4 = kTrigEntries * 2 / 4;  // the table as float4s
+static_assert(kTrigEntries * 2 % 4 == 0 && kTrigVec4 <= kBlock, "one float4 per thread stages the table");
+__global__ __launch_bounds__(kBlock) void fill_trig_table_kernel(float* table) {
   for (int idx = threadIdx.x; idx < kTrigEntries; idx += kBlock) {
     float sv, cv;
     sincos_deg((float)(idx - kTrigBias), sv, cv);
-    trig[idx] = SinCos{sv, cv};
+    table[2 * idx] = sv;
+    table[2 * idx + 1] = cv;
   }
+}
+__device__ __forceinline__ float4 trig_table_load(const float* table) {
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (threadIdx.x < kTrigVec4) v = reinterpret_cast<const float4*>(table)[threadIdx.x];
+  return v;
+}
+// every wave of the block executes this exactly once (the barrier counts arrivals, wherever the s_barrier sits)
+__device__ __forceinline__ void trig_table_commit(SinCos* lds, const float4& v) {
+  if (threadIdx.x < kTrigVec4) reinterpret_cast<float4*>(lds)[threadIdx.x] = v;
   __syncthreads();
 }
 template <class Tbl, bool TABLE>
@@ -434,11 +449,33 @@ struct PoseCache {
   float zmin;        // min z of its last two frames
 };
 
+// sines / cosines of joints 1 .. JN-1 at the pose a step starts from: out of the whole-degree table when the host
+// knows every angle of the batch to be a whole degree in [-180, 180) (kFlagWholeGoals, wave-uniform), else computed.
+// The table holds sincos_deg of the very float g + off, so both ways give the same bits.
+template <class Tbl, bool TABLE>
+__device__ __forceinline__ void prev_pose_sincos(const Tbl& t, const float (&g)[Tbl::D], float (&sF)[Tbl::D],
+                                                 float (&cF)[Tbl::D], const SinCos* trig, bool whole) {
+  constexpr int JN = ZJoints<Tbl>::value;
+  if constexpr (TABLE) {
+    if (whole) {
+#pragma unroll
+      for (int j = 1; j < JN; ++j) {
+        const SinCos v = trig[(int)g[j] + ((int)Tbl::off(j) + kTrigBias)];
+        sF[j] = v.s;
+        cF[j] = v.c;
+      }
+      return;
+    }
+  }
+#pragma unroll
+  for (int j = 1; j < JN; ++j) sincos_deg(g[j] + t.off(j), sF[j], cF[j]);
+}
+
 template <class Tbl, int TRIG, bool CACHED = false, bool TABLE = false>
 __device__ __forceinline__ float route_kinematics(const Tbl& t, int S, float inv_sm1, const float (&g)[Tbl::D],
                                                   const float (&act)[Tbl::D], float (&el)[3], float (&e)[3],
                                                   PoseCache<Tbl::D>* cache = nullptr, bool cache_valid = false,
-                                                  const SinCos* trig = nullptr) {
+                                                  const SinCos* trig = nullptr, bool prev_whole = false) {
   constexpr int D = Tbl::D;
   constexpr int JN = ZJoints<Tbl>::value;
   constexpr bool kSequential = (TRIG == 0 || TRIG == 5) && D >= 6;
@@ -469,8 +506,7 @@ __device__ __forceinline__ float route_kinematics(const Tbl& t, int S, float inv
         }
         zmin = cache->zmin;
       } else {
-#pragma unroll
-        for (int j = 1; j < JN; ++j) sincos_deg(g[j] + t.off(j), sF[j], cF[j]);
+        prev_pose_sincos<Tbl, TABLE>(t, g, sF, cF, trig, prev_whole);
         chain_z<Tbl>(sF, cF, t, zo, ze);
         zmin = fminf(zo, ze);
       }
@@ -528,8 +564,7 @@ __device__ __forceinline__ float route_kinematics(const Tbl& t, int S, float inv
     }
     zmin = fminf(zmin, cache->zmin);
   } else {
-#pragma unroll
-    for (int j = 1; j < JN; ++j) sincos_deg(g[j] + t.off(j), sF[j], cF[j]);
+    prev_pose_sincos<Tbl, TABLE>(t, g, sF, cF, trig, prev_whole);
     chain_z<Tbl>(sF, cF, t, zo, ze);
     zmin = fminf(zmin, fminf(zo, ze));
   }
@@ -633,10 +668,21 @@ constexpr int step_min_waves() { return (TRIG == 0 && Tbl::D >= 6 && Tbl::D <= 7
 //            measured and is slower at every batch size: profiles/r02_variants.md section 5.)
 constexpr int kPrefetch = 8;
 
-template <class Tbl, bool SAMPLE, int TRIG, bool LDS, int PF = 0>
+//   TT     : sampled actions are whole degrees, and so is the pose they leave behind: with a compile-time table (whole-
+//            degree joint offsets) the sines / cosines of BOTH end poses of the route come out of the 450-entry
+//            whole-degree table (fill_trig_table_kernel), staged into LDS per block, instead of 2 (JN - 1) + 1 range
+//            reductions and polynomials per env -- 13 % of the kernel's instructions for the reference arm, which is what
+//            matters where the launch is VALU-issue-bound (the 131 072 .. 262 144-arm shards of a strong-scaled job).
+//            Whole batch only (threads past the end of the batch run up to the barrier: their loads stay inside the
+//            rows, which are ld >= round_up(n, 256) long); same bits as the computed values.
+template <class Tbl, bool SAMPLE, int TRIG, bool LDS, int PF = 0, bool TT = false>
 __global__ __launch_bounds__(kBlock, (PF ? 1 : step_min_waves<Tbl, TRIG>())) void step_kernel(const StepArgs a) {
   constexpr int D = Tbl::D;
+  static_assert(!TT || (SAMPLE && TRIG == 0 && !LDS && ActionTrigTable<Tbl>::value), "the table serves sampled actions of a static table");
   __shared__ DhConst sh;
+  __shared__ __attribute__((aligned(16))) SinCos trig_lds[TT ? kTrigEntries : 1];
+  float4 trig_v;
+  if (TT) trig_v = trig_table_load(a.trig_table);
   if (LDS) {
     const float* src = reinterpret_cast<const float*>(&a.dh);
     float* dst = reinterpret_cast<float*>(&sh);
@@ -646,7 +692,7 @@ __global__ __launch_bounds__(kBlock, (PF ? 1 : step_min_waves<Tbl, TRIG>())) voi
   const Tbl t = TableMaker<Tbl>::make(LDS ? sh : a.dh);
 
   const uint32_t i = blockIdx.x * kBlock + threadIdx.x;  // 32-bit lane offset: rows are addressed as uniform base + i
-  if (i >= a.n) return;
+  if (!TT && i >= a.n) return;
   const int64_t ld = a.ld;
 
   // Long arms (D >= 6) are register-bound: their kernel keeps nothing alive across the sub-step loops that it can
@@ -691,13 +737,18 @@ __global__ __launch_bounds__(kBlock, (PF ? 1 : step_min_waves<Tbl, TRIG>())) voi
     }
   }
   MT_STAMP(a, i, 1);  // action known (Philox done / staged action loaded)
+  if (TT) {
+    trig_table_commit(trig_lds, trig_v);  // the table load has had the pose loads and the Philox block to arrive
+    if (i >= a.n) return;
+  }
   if (kLean) {  // goals = action (manytor.py:184): the old pose is in registers already
 #pragma unroll
     for (int j = 0; j < D; ++j) str(a.goals + j * ld, i * 4u, act[j]);
   }
 
   float el[3], e[3];
-  const float zmin = route_kinematics<Tbl, TRIG>(t, a.S, a.inv_sm1, g, act, el, e);
+  const float zmin = route_kinematics<Tbl, TRIG, false, TT>(t, a.S, a.inv_sm1, g, act, el, e, nullptr, false, trig_lds,
+                                                            (a.flags & kFlagWholeGoals) != 0);
   const bool ground = zmin < 0.f;  // manytor.py:191
   if (a.zmin) str_stream(a.zmin, i * 4u, zmin);  // MT_FLAG_DEBUG_ZMIN: wave-uniform branch on an SGPR pointer, NULL by default
   if (kLean && !PF) {
@@ -761,7 +812,8 @@ template <class Tbl, int L, bool CACHED, bool TABLE = false>
 __device__ __forceinline__ float route_kinematics_split(const Tbl& t, int S, float inv_sm1, const float (&g)[Tbl::D],
                                                         const float (&act)[Tbl::D], bool backward, float (&el)[3],
                                                         float (&e)[3], PoseCache<Tbl::D>* cache = nullptr,
-                                                        bool cache_valid = false, const SinCos* trig = nullptr) {
+                                                        bool cache_valid = false, const SinCos* trig = nullptr,
+                                                        bool prev_whole = false) {
   constexpr int D = Tbl::D;
   constexpr int JN = ZJoints<Tbl>::value;
   constexpr int EPW = 64 / L;
@@ -788,8 +840,7 @@ __device__ __forceinline__ float route_kinematics_split(const Tbl& t, int S, flo
     }
     z0 = cache->zmin;
   } else {
-#pragma unroll
-    for (int j = 1; j < JN; ++j) sincos_deg(g[j] + t.off(j), sF[j], cF[j]);
+    prev_pose_sincos<Tbl, TABLE>(t, g, sF, cF, trig, prev_whole);
     chain_z<Tbl>(sF, cF, t, zo, ze);
     z0 = fminf(zo, ze);
   }
@@ -843,18 +894,25 @@ __device__ __forceinline__ float route_kinematics_split(const Tbl& t, int S, flo
 //   stores        : each sub-lane its targets' observations; sub-lane 0 the env's state and step outputs
 // Only the default trigonometry (TRIG 0); D, the table kinds and both action sources as in step_kernel.
 // ---------------------------------------------------------------------------
-template <class Tbl, bool SAMPLE, int L>
+template <class Tbl, bool SAMPLE, int L, bool TT = false>
 __global__ __launch_bounds__(kBlock) void step_split_kernel(const StepArgs a) {
   static_assert(L == 2 || L == 4, "an env is spread over 2 or 4 lanes");
+  static_assert(!TT || (SAMPLE && ActionTrigTable<Tbl>::value), "the table serves sampled actions of a static table");
   constexpr int D = Tbl::D;
   constexpr int EPW = 64 / L;                                  // envs per wave
   constexpr int PFS = (kPrefetch + L - 1) / L;                 // targets per sub-lane requested up front
+  __shared__ __attribute__((aligned(16))) SinCos trig_lds[TT ? kTrigEntries : 1];   // as in step_kernel<.., TT>
+  float4 trig_v;
+  if (TT) trig_v = trig_table_load(a.trig_table);
   const Tbl t = TableMaker<Tbl>::make(a.dh);
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
   const uint32_t q = lane / EPW;
   const int64_t first = (int64_t)wave * EPW;                   // first env of this wave
-  if (first >= a.n) return;                                    // whole wave beyond the batch
+  if (first >= a.n) {                                          // whole wave beyond the batch
+    if (TT) trig_table_commit(trig_lds, trig_v);               // its arrival at the block's barrier, and its quarter of the table
+    return;
+  }
   const uint32_t env = (uint32_t)first + lane % EPW;
   const bool live = env < a.n;                                 // tail lanes compute on the last env and store nothing
   const uint32_t i = live ? env : (uint32_t)(a.n - 1);
@@ -892,9 +950,12 @@ __global__ __launch_bounds__(kBlock) void step_split_kernel(const StepArgs a) {
     }
   }
 
+  if (TT) trig_table_commit(trig_lds, trig_v);
+
   // ---- kinematics: the poses of route_kinematics, one half per sub-lane parity ------------------------------
   float el[3], e[3];
-  const float zmin = route_kinematics_split<Tbl, L, false>(t, a.S, a.inv_sm1, g, act, (q & 1u) != 0, el, e);
+  const float zmin = route_kinematics_split<Tbl, L, false, TT>(t, a.S, a.inv_sm1, g, act, (q & 1u) != 0, el, e, nullptr, false,
+                                                                trig_lds, (a.flags & kFlagWholeGoals) != 0);
   const bool ground = zmin < 0.f;  // manytor.py:191
   if (a.zmin && live && q == 0) __builtin_nontemporal_store(zmin, a.zmin + i);  // MT_FLAG_DEBUG_ZMIN
 
@@ -1249,14 +1310,14 @@ struct RolloutArgs {
 
 template <class Tbl>
 __global__ __launch_bounds__(kBlock) void rollout_kernel(const StepArgs a, const RolloutArgs r) {
-  extern __shared__ float tile[];  // [3K][kBlock] (+ the action sin / cos table for the compile-time tables)
+  extern __shared__ __attribute__((aligned(16))) float tile[];  // [3K][kBlock] (+ the action sin / cos table for the compile-time tables)
   constexpr int D = Tbl::D;
   constexpr bool kTable = ActionTrigTable<Tbl>::value;
   const Tbl t = TableMaker<Tbl>::make(a.dh);
   const SinCos* trig = nullptr;
   if constexpr (kTable) {
     SinCos* w = reinterpret_cast<SinCos*>(tile + 3 * a.K * kBlock);
-    fill_action_trig(w);
+    trig_table_commit(w, trig_table_load(a.trig_table));
     trig = w;
   }
   const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
@@ -1281,7 +1342,8 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(const StepArgs a, const
   for (int s = 0; s < r.T; ++s) {
     float act[D], el[3], e[3];
     draw_action<D>(seed, env_id, r.step0 + (uint32_t)s, act);
-    const float zmin = route_kinematics<Tbl, 0, true, kTable>(t, a.S, a.inv_sm1, g, act, el, e, &pose, pose_valid, trig);
+    const float zmin = route_kinematics<Tbl, 0, true, kTable>(t, a.S, a.inv_sm1, g, act, el, e, &pose, pose_valid, trig,
+                                                              (a.flags & kFlagWholeGoals) != 0 || s > 0);
     pose_valid = true;
     const bool ground = zmin < 0.f;
     if (a.zmin) str_stream(a.zmin, i * 4u, zmin);  // MT_FLAG_DEBUG_ZMIN (a step output like reward: the last step's stays)
@@ -1358,7 +1420,7 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(const StepArgs a, const
 template <class Tbl, int L>
 __global__ __launch_bounds__(kBlock) void rollout_split_kernel(const StepArgs a, const RolloutArgs r) {
   static_assert(L == 2 || L == 4, "an env is spread over 2 or 4 lanes");
-  extern __shared__ float tile[];  // [3K][kBlock / L] (+ the action sin / cos table for the compile-time tables)
+  extern __shared__ __attribute__((aligned(16))) float tile[];  // [3K][kBlock / L] (+ the action sin / cos table for the compile-time tables)
   constexpr int D = Tbl::D;
   constexpr int EPW = 64 / L;
   constexpr int EPB = kBlock / L;  // envs per block = columns of the tile
@@ -1367,7 +1429,7 @@ __global__ __launch_bounds__(kBlock) void rollout_split_kernel(const StepArgs a,
   const SinCos* trig = nullptr;
   if constexpr (kTable) {
     SinCos* w = reinterpret_cast<SinCos*>(tile + 3 * a.K * EPB);
-    fill_action_trig(w);
+    trig_table_commit(w, trig_table_load(a.trig_table));
     trig = w;
   }
   const uint32_t lane = threadIdx.x & 63u;
@@ -1403,7 +1465,8 @@ __global__ __launch_bounds__(kBlock) void rollout_split_kernel(const StepArgs a,
   for (int s = 0; s < r.T; ++s) {
     float act[D], el[3], e[3];
     draw_action<D>(seed, env_id, r.step0 + (uint32_t)s, act);
-    const float zmin = route_kinematics_split<Tbl, L, true, kTable>(t, a.S, a.inv_sm1, g, act, backward, el, e, &pose, pose_valid, trig);
+    const float zmin = route_kinematics_split<Tbl, L, true, kTable>(t, a.S, a.inv_sm1, g, act, backward, el, e, &pose, pose_valid,
+                                                                    trig, (a.flags & kFlagWholeGoals) != 0 || s > 0);
     pose_valid = true;
     const bool ground = zmin < 0.f;
     if (a.zmin && live && q == 0) __builtin_nontemporal_store(zmin, a.zmin + i);  // MT_FLAG_DEBUG_ZMIN

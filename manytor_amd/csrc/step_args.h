@@ -9,6 +9,11 @@ namespace mt {
 
 constexpr int kBlock = 256;  // 4 wavefronts
 
+// Internal bit of StepArgs::flags (never accepted from mt_config): every env's joint angles are whole degrees in
+// [-180, 180) -- true after a reset and while only in-kernel sampled actions have been applied since (the host tracks
+// it) -- so the kernels may take the sines / cosines of the pose a step starts from out of the whole-degree table.
+constexpr uint32_t kFlagWholeGoals = 0x80000000u;
+
 // Per-joint DH constants, uniform over the launch.  Passed by value in the
 // kernel arguments, so they live in SGPRs (s_load from the kernarg segment);
 // the MT_FLAG_DH_IN_LDS variant copies them to LDS first.
@@ -36,6 +41,7 @@ struct StepArgs {
   float* last_return;             // [ld] return of the episode that ended at the last (auto-)reset
   float* ring;                    // [ring_slots][ld] returns of the episodes an env finished, slot = finished count % ring_slots
   uint32_t* bad_actions;          // [1] number of (env, step) pairs whose staged action was not a usable angle
+  const float* trig_table;        // [450][2] (sin, cos) of the whole degrees -270 .. 179, filled once at mt_create (kernels.h: SinCos)
   float* zmin;                    // [ld] MT_FLAG_DEBUG_ZMIN only (else NULL): the z-minimum the ground test of the last step used
   uint32_t ring_slots, episode0;  // episode0 = episode index every env got at the last full reset
   int64_t n, ld, env_base;

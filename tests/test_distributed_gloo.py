@@ -170,6 +170,8 @@ class _FakeEngine:
     """Stand-in for StepEngine in bench.EpisodeLoop: returns = number of steps since the last reset + global env id /
     1e6, gathered over gloo.  Lets the CPU check count what the GPU run would launch."""
 
+    tag_ids = True                                        # returns carry the global env id in their fraction
+
     def __init__(self, n_total, rank, world):
         self.n_total = n_total
         self.base, self.n = D.shard_range(n_total, rank, world)
@@ -189,7 +191,7 @@ class _FakeEngine:
 
     def gather_returns(self, out=None):
         self.gathers += 1
-        ids = torch.arange(self.base, self.base + self.n, dtype=torch.float32)
+        ids = torch.arange(self.base, self.base + self.n, dtype=torch.float32) if self.tag_ids else 0.0
         return D.gloo_gather_returns(self.ret + ids / 1e6, self.n_total)
 
     gather_begin = gather_returns
@@ -197,11 +199,25 @@ class _FakeEngine:
     def gather_wait(self, host=False):
         return 0.0 if host else None
 
-    def lap_begin(self, what):
+    def lap_begin(self, what=None):
         self.laps.append(what)
 
-    def lap_end(self, what):
+    def lap_end(self, what=None):
         assert self.laps[-1] == what
+
+    # the rest of what bench.measure / bench.TimedEngine ask of an engine
+    def lap_times(self):
+        n, self.laps = len(self.laps), []
+        return [0.05] * n                                 # "device milliseconds" per lap
+
+    def sync(self):
+        pass
+
+    def total_reward(self):
+        return self.ret.numpy()
+
+    def total_envs(self):
+        return self.n_total
 
 
 def _bench_loop_worker(rank, world, port, steps, warmup, q):
@@ -238,3 +254,40 @@ def test_bench_episode_loop_world2_gloo(steps, warmup):
     ids = np.arange(1001, dtype=np.float32) / np.float32(1e6)
     np.testing.assert_allclose(g - ids, np.full(1001, L), atol=1e-3)      # a full episode's return from every env
     assert launches == max(L, 200) + warmup + 3 * steps and resets == gathers + 1
+
+
+def _measure_worker(rank, world, port, steps, warmup, q):
+    sys.path.insert(0, ROOT)
+    import bench
+    r, _, w = _init(rank, world, port)
+    bar = D.make_host_barrier(r, w)
+    fab = bench.Fabric(r, w, dist, torch, "cpu", bar, None)
+    out = {}
+    for key, n_total in (("weak", 2 * 600), ("strong_1m", 1001), ("config3", 4003)):     # ragged strong shards
+        eng = _FakeEngine(n_total, r, w)
+        eng.tag_ids = False                               # bench.measure checks that returns are whole numbers
+        res = bench.measure(fab, eng, n_total, steps, warmup, 50, 0x5EED, prewarm_s=0.02, min_timed_s=0.001)
+        out[key] = (res, eng.launches, eng.gathers)
+    if r == 0:
+        q.put(out)
+    dist.barrier()
+    bar.close()
+    dist.destroy_process_group()
+
+
+def test_bench_measure_protocol_world2_gloo():
+    """bench.measure + bench.Fabric -- the protocol every leg of an N > 1 invocation goes through (headline, the 1 M-arm
+    strong leg, configs[3]) -- at world size 2 over gloo with the shared-memory barrier: every region launches exactly
+    `steps` steps and contains a gather, the figures every leg reports are there, and both ranks agree on the number of
+    regions (rank 0's clock decides the time-based loops)."""
+    out = _spawn(_measure_worker, (20, 5))
+    for key, (res, launches, gathers) in out.items():
+        for k in ("elapsed", "ms_per_step", "ms_per_step_min", "ms_per_step_max", "step_us", "launches", "gather_us",
+                  "gathers_per_region", "repeats", "prewarm", "episode_len", "value"):
+            assert k in res, (key, k)
+        assert res["episode_len"] == 20 and res["gathers_per_region"] == 1 and res["repeats"] >= 5
+        assert res["launches"] == 20 * res["repeats"]
+        assert launches == res["prewarm"] + 5 + 20 * res["repeats"]
+        assert res["ms_per_step_min"] <= res["ms_per_step"] <= res["ms_per_step_max"]
+        # 5 warm-up steps put the episode boundary inside every region: two step segments = two 0.05 ms laps per region
+        assert res["step_us"] == pytest.approx(2 * 50.0 / 20)

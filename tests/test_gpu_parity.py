@@ -1112,3 +1112,39 @@ def test_large_multienv_returns_views_not_lists(m):
     assert obs2.torch().shape == (8192, 21)
     assert isinstance(me.environment[5].total_reward, float)
     assert len(me.environment) == 8192
+
+
+@pytest.mark.parametrize("graph", [0, 1])
+@pytest.mark.parametrize("chains", [2, 3, 4])
+@pytest.mark.parametrize("n,k,table_name", [(100003, 7, "ref"), (777, 3, "ref"), (300, 2, "ref"), (70001, 5, "dh7"),
+                                            (262144, 7, "ref")])
+def test_rollout_in_independent_chains_equals_plain_launches(m, monkeypatch, n, k, table_name, chains, graph):
+    """mt_rollout may run as several chains of launches -- contiguous 256-aligned env ranges on separate streams, forked
+    from and joined to the handle's stream (MT_CHAINS; engine.hip: launch_chained_steps), also inside the cached HIP
+    graph -- because a step of env i depends only on env i.  Same kernels on row views + the global env id in the RNG
+    key => every field equal bit for bit to the single-stream sequence, ragged tails and tiny batches included; and
+    work queued on the handle's stream right behind the rollout sees the joined result."""
+    table = m.REF_DH_TABLE if table_name == "ref" else m.DH7_TABLE
+    radius = 51.3 if table_name == "ref" else 92.6
+    fields = STATE_FIELDS + STEP_FIELDS
+    monkeypatch.setenv("MT_CHAINS", "1")
+    monkeypatch.setenv("MT_GRAPH", "0")
+    ref = m.StepEngine(n, k, dh_table=table, radius=radius, pickup_tol=20.0)
+    ref.reset_random(6, 0)
+    ref.rollout(9, 6, 0)
+    ref.reset_done(6)
+    ref.rollout(9, 6, 9)
+    want = {f: ref.get(getattr(m.lib, f)) for f in fields}
+    monkeypatch.setenv("MT_CHAINS", str(chains))
+    monkeypatch.setenv("MT_GRAPH", str(graph))
+    e = m.StepEngine(n, k, dh_table=table, radius=radius, pickup_tol=20.0)
+    e.reset_random(6, 0)
+    e.rollout(9, 6, 0)
+    e.reset_done(6)                          # queued on the handle's stream: must see every chain's last step
+    e.rollout(9, 6, 9)                       # second request of the segment length: the cached graph when graph = 1
+    for f, v in want.items():
+        np.testing.assert_array_equal(e.get(getattr(m.lib, f)), v, err_msg=f)
+    e.rollout(9, 6, 18)                      # and once more through the (now certainly cached) graph / plain chains
+    ref.rollout(9, 6, 18)
+    for f in fields:
+        np.testing.assert_array_equal(e.get(getattr(m.lib, f)), ref.get(getattr(m.lib, f)), err_msg=f)

@@ -62,10 +62,14 @@ def timing_fused(split, n, steps=600):
     return round(tot * 1e3 / (steps // 50 * 50), 3)
 
 
-def timing(split, prefetch, n, steps=600):
+def timing(split, prefetch, n, steps=600, trig_table=None, **kw):
     os.environ["MT_SPLIT"] = str(split)
     os.environ["MT_PREFETCH"] = str(prefetch)
-    e = m.StepEngine(n, 7)
+    if trig_table is None:
+        os.environ.pop("MT_TRIG_TABLE", None)
+    else:
+        os.environ["MT_TRIG_TABLE"] = str(int(trig_table))
+    e = m.StepEngine(n, 7, **kw)
     e.reset_random(1, 0)
     t0 = time.perf_counter()
     ep = 0
