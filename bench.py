@@ -36,7 +36,7 @@ sys.path.insert(0, ROOT)
 
 METRIC = "env-steps/sec (whole node), 1M parallel 4-DoF arms, random actions"
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
-MIN_TIMED_S = 0.05           # the repeated timed regions together cover at least this much GPU work
+MIN_TIMED_S = 0.25           # the repeated timed regions together cover at least this much GPU work (5..300 regions)
 PREWARM_S = 0.3
 
 
@@ -215,6 +215,31 @@ class EpisodeLoop:
         self._bufs = [None, None]
         self.eng.reset_random(seed, 0)
 
+    def align(self):
+        """End the running episode now (gather + reset, as at a regular episode end), so that the next step is the first of
+        an episode.  bench.measure() calls it between the untimed warm-up steps and the first timed region: a region of
+        K = episode_len steps is then ONE rollout segment followed by its gather and reset, not two segments around an
+        episode boundary left wherever the warm-up happened to stop."""
+        if self.step % self.L:
+            self.step += self.L - self.step % self.L
+            self._episode_end(False)
+
+    def _episode_end(self, time_kernels):
+        if self.overlap:
+            self.eng.gather_wait()                   # stream order only: the previous exchange finished long ago
+            b = self.gathers % 2
+            self._bufs[b] = self.gathered = self.eng.gather_begin(self._bufs[b])
+            self.gathers += 1
+        else:
+            if time_kernels:
+                self.eng.lap_begin("gather")
+            self.gathered = self.eng.gather_returns(self.gathered)     # RCCL all-gather (device copy at N = 1)
+            if time_kernels:
+                self.eng.lap_end("gather")
+            self.gathers += 1
+        self.episode += 1
+        self.eng.reset_random(self.seed, self.episode)
+
     def run(self, count, time_kernels=False):
         """`count` env steps.  Returns (step launches timed, gathers done) of this call."""
         done = launches = gathers = 0
@@ -232,21 +257,8 @@ class EpisodeLoop:
             self.step += seg
             done += seg
             if self.step % self.L == 0:
-                if self.overlap:
-                    self.eng.gather_wait()                   # stream order only: the previous exchange finished long ago
-                    b = self.gathers % 2
-                    self._bufs[b] = self.gathered = self.eng.gather_begin(self._bufs[b])
-                    self.gathers += 1
-                else:
-                    if time_kernels:
-                        self.eng.lap_begin("gather")
-                    self.gathered = self.eng.gather_returns(self.gathered)     # RCCL all-gather (device copy at N = 1)
-                    if time_kernels:
-                        self.eng.lap_end("gather")
-                    self.gathers += 1
+                self._episode_end(time_kernels)
                 gathers += 1
-                self.episode += 1
-                self.eng.reset_random(self.seed, self.episode)
         return launches, gathers
 
 
@@ -404,8 +416,9 @@ def measure(fab, raw, n_total, steps, warmup, episode_len, seed, fused=False, ov
         prewarm += max(L, 200)
         raw.sync()
     est_s = float(fab.max_over_ranks([(time.perf_counter() - t0) / max(1, prewarm) * steps])[0])   # one region, estimated
-    reps = repeats or int(min(100, max(5, math.ceil(min_timed_s / max(est_s, 1e-6)))))
+    reps = repeats or int(min(300, max(5, math.ceil(min_timed_s / max(est_s, 1e-6)))))
     loop.run(warmup)                                            # the W untimed warm-up steps of the contract
+    loop.align()                                                # the first timed region starts an episode
     fab.fence(raw)
     regions, kernel_ms, gather_ms, launches, gathers = [], 0.0, 0.0, 0, 0
     for _ in range(reps):
@@ -448,7 +461,7 @@ def main():
     ap.add_argument("--dof", type=int, default=4, choices=(4, 7))
     ap.add_argument("--targets", type=int, default=7)
     ap.add_argument("--episode-len", type=int, default=50)       # test_multi.py:8
-    ap.add_argument("--repeats", type=int, default=0, help="timed regions (0 = enough for >= 50 ms of GPU work, 5..100)")
+    ap.add_argument("--repeats", type=int, default=0, help="timed regions (0 = enough for >= 250 ms of GPU work, 5..300)")
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x5EED)
     ap.add_argument("--sync-gather", action="store_true",
                     help="run the return gather in line on the engine's stream instead of overlapped on its side stream")

@@ -1143,15 +1143,89 @@ __global__ __launch_bounds__(kBlock) void sample_actions_kernel(float* actions, 
 // reset (manytor.py:219-253).  RANDOM: draw the targets here; otherwise the
 // caller has already filled `points`.  ONLY_DONE: re-arm finished envs only.
 // ---------------------------------------------------------------------------
+// The draw of reset_kernel, shared by the 64 envs of a wave.  Rejection sampling makes the lanes of a wave need different
+// numbers of Philox blocks (6.7 on average for K = 7, ~13 for the unluckiest of 64), and a wave runs as long as its
+// unluckiest lane.  So: while more than half of the lanes still need targets every lane draws for itself, one block per
+// trip; once m <= 32 lanes are still needy, the whole wave works for them -- the 64 lanes are cut into m groups of
+// h = 64 / m lanes, group g serves the g-th needy lane T and evaluates T's NEXT h blocks at once (lane r of the group:
+// block blk_T + r), the accepted candidates are numbered in (block, half) order with two ballots and written straight
+// into T's LDS column.  That is exactly the sequential order of draw_targets, so the targets are the same bits; the wave
+// finishes in ~9 trips instead of ~13, and a reset_done with few finished envs in one or two.
+// `need` = this lane's env wants targets; `col0` = the LDS column of the wave's lane 0 ([3K][kBlock] floats per block).
+__device__ __forceinline__ void draw_targets_wave(uint64_t seed, uint64_t env0, uint32_t episode, bool need, int K, float radius,
+                                                  float* col0, uint8_t* slots) {
+  const uint32_t lane = threadIdx.x & 63u;
+  auto put = [&](uint32_t t, int k, float x, float y, float z) {
+    float* cell = col0 + t + 3 * k * kBlock;
+    cell[0] = x;
+    cell[kBlock] = y;
+    cell[2 * kBlock] = z;
+  };
+  int cnt = need ? 0 : K;
+  uint32_t blk = 0;
+  unsigned long long M = __ballot(cnt < K);
+  for (int trip = 0; M != 0ull && trip < 4096; ++trip) {
+    const int m = __popcll(M);
+    if (m > 32) {  // every needy lane for itself: one block, two candidates (draw_targets' loop body)
+      if (cnt < K) {
+        const u32x4 w = stream_block(seed, env0 + lane, kTagTarget, episode, blk);
+        float x, y, z;
+        if (target_candidate<0>(w, radius, x, y, z)) put(lane, cnt++, x, y, z);
+        if (cnt < K && target_candidate<1>(w, radius, x, y, z)) put(lane, cnt++, x, y, z);
+        ++blk;
+      }
+    } else {
+      const uint32_t h = 64u / (uint32_t)m;                                   // lanes per needy lane: 2 .. 64
+      const bool needy = cnt < K;
+      const uint32_t rank = (uint32_t)__popcll(M & ((1ull << lane) - 1ull));  // needy lane -> its group
+      if (needy) slots[rank] = (uint8_t)lane;
+      __builtin_amdgcn_wave_barrier();
+      const uint32_t g = lane / h, r = lane % h;
+      const bool serving = g < (uint32_t)m;
+      const uint32_t T = serving ? slots[g] : 0u;
+      __builtin_amdgcn_wave_barrier();                                        // all reads done before the next trip's writes
+      const uint32_t blkT = (uint32_t)__shfl((int)blk, (int)T);
+      const int cntT = __shfl(cnt, (int)T);
+      const uint32_t epT = (uint32_t)__shfl((int)episode, (int)T);
+      bool a0 = false, a1 = false;
+      float x0 = 0.f, y0 = 0.f, z0 = 0.f, x1 = 0.f, y1 = 0.f, z1 = 0.f;
+      if (serving) {
+        const u32x4 w = stream_block(seed, env0 + T, kTagTarget, epT, blkT + r);
+        a0 = target_candidate<0>(w, radius, x0, y0, z0);
+        a1 = target_candidate<1>(w, radius, x1, y1, z1);
+      }
+      const unsigned long long A0 = __ballot(a0), A1 = __ballot(a1);
+      auto group_mask = [&](uint32_t grp) { return (h == 64u ? ~0ull : ((1ull << h) - 1ull)) << (grp * h); };
+      if (serving) {  // number my candidates behind those of the lower lanes of my group: (block, half) order
+        const unsigned long long lower = group_mask(g) & ((1ull << lane) - 1ull);
+        const int k0 = cntT + __popcll(A0 & lower) + __popcll(A1 & lower);
+        if (a0 && k0 < K) put(T, k0, x0, y0, z0);
+        const int k1 = k0 + (a0 ? 1 : 0);
+        if (a1 && k1 < K) put(T, k1, x1, y1, z1);
+      }
+      if (needy) {  // what my group found for me
+        const unsigned long long gm = group_mask(rank);
+        cnt += __popcll(A0 & gm) + __popcll(A1 & gm);
+        blk += h;
+      }
+    }
+    M = __ballot(cnt < K);
+  }
+  for (; cnt < K; ++cnt) put(lane, cnt, 0.f, 0.f, 0.5f * radius);  // unreachable in practice, as in draw_targets
+  __builtin_amdgcn_wave_barrier();  // a lane's column was written by other lanes of its wave
+}
+
 template <int D, bool RANDOM, bool ONLY_DONE>
 __global__ __launch_bounds__(kBlock) void reset_kernel(const StepArgs a, float radius) {
   const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-  if (i >= a.n) return;
+  const bool valid = i < a.n;
+  if (!RANDOM && !valid) return;  // with RANDOM every lane of a wave takes part in the draw (draw_targets_wave)
   const int64_t ld = a.ld;
   // done byte: 1 = finished, waiting for this call; 2 = finished and already re-armed inside mt_rollout_fused
-  const uint8_t dn = ONLY_DONE ? a.done[i] : (uint8_t)1;
+  const uint8_t dn = !valid ? (uint8_t)0 : (ONLY_DONE ? a.done[i] : (uint8_t)1);
   const bool go = dn == 1;
   if (ONLY_DONE && dn == 2) a.done[i] = 0;
+  uint32_t episode = a.major;
   if (go) {
     float s[D], c[D], p[D][3];
 #pragma unroll
@@ -1174,27 +1248,27 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(const StepArgs a, float r
     a.done[i] = 0;
     a.alive[i] = (a.K >= 32) ? 0xFFFFFFFFu : ((1u << a.K) - 1u);
     // full reset: the caller names the episode; re-arm of a finished env: its own counter advances by one
-    const uint32_t episode = ONLY_DONE ? a.episodes[i] + 1u : a.major;
+    if (ONLY_DONE) episode = a.episodes[i] + 1u;
     a.episodes[i] = episode;
-    if (RANDOM) {
-      // manytor.py:229-239: uniform in the cube, keep z >= 0 and |p| <= radius.  z is drawn from
-      // [0, R) directly (same conditional law).  fp32, one rounding per op, mirrored by oracle/philox_ref.py.
-      // Envs of one wave accept their k-th target at different candidates, so storing from inside the draw loop
-      // would write partial lines of different rows per instruction.  The accepted targets are parked in this
-      // thread's LDS column ([3K][kBlock] floats, conflict-free) and written out row by row afterwards.
-      extern __shared__ float stage[];
-      float* col = stage + threadIdx.x;
-      const uint64_t seed = ((uint64_t)a.seed_hi << 32) | a.seed_lo;
-      draw_targets(seed, (uint64_t)(a.env_base + i), episode, a.K, radius, [&](int k, float x, float y, float z) {
-        float* cell = col + 3 * k * kBlock;
-        cell[0] = x;
-        cell[kBlock] = y;
-        cell[2 * kBlock] = z;
-      });
+  }
+  if (RANDOM) {
+    // manytor.py:229-239: uniform in the cube, keep z >= 0 and |p| <= radius.  z is drawn from
+    // [0, R) directly (same conditional law).  fp32, one rounding per op, mirrored by oracle/philox_ref.py.
+    // Envs of one wave accept their k-th target at different candidates, so storing from inside the draw loop
+    // would write partial lines of different rows per instruction.  The accepted targets are parked in the env's
+    // LDS column ([3K][kBlock] floats, conflict-free) and written out row by row afterwards.
+    extern __shared__ float stage[];
+    __shared__ uint8_t slots[kBlock / 64][64];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t seed = ((uint64_t)a.seed_hi << 32) | a.seed_lo;
+    draw_targets_wave(seed, (uint64_t)(a.env_base + (i - lane)), episode, go, a.K, radius, stage + (threadIdx.x - lane),
+                      slots[threadIdx.x >> 6]);
+    if (go) {
+      const float* col = stage + threadIdx.x;
       for (int r = 0; r < 3 * a.K; ++r) (a.points + (int64_t)r * ld)[i] = col[r * kBlock];
     }
   }
-  if ((threadIdx.x & 63) == 0) a.done_bits[i >> 6] = 0ull;  // every env of the wave has done == 0 now
+  if (valid && (threadIdx.x & 63) == 0) a.done_bits[i >> 6] = 0ull;  // every env of the wave has done == 0 now
 }
 
 // reset with the draw of an env's targets spread over L lanes of a wave -- for batches so small that the kernel's time

@@ -289,5 +289,5 @@ def test_bench_measure_protocol_world2_gloo():
         assert res["launches"] == 20 * res["repeats"]
         assert launches == res["prewarm"] + 5 + 20 * res["repeats"]
         assert res["ms_per_step_min"] <= res["ms_per_step"] <= res["ms_per_step_max"]
-        # 5 warm-up steps put the episode boundary inside every region: two step segments = two 0.05 ms laps per region
-        assert res["step_us"] == pytest.approx(2 * 50.0 / 20)
+        # the loop is aligned after the warm-up, so a 20-step region is ONE step segment = one 0.05 ms lap
+        assert res["step_us"] == pytest.approx(50.0 / 20)
