@@ -585,24 +585,30 @@ def main():
         return ("in line on the engine's stream" if args.sync_gather else
                 "overlapped: snapshot + exchange on the engine's side stream (mt_gather_returns_begin)")
 
-    def secondary_leg(n_total, fused, label):
-        """A further (strong-scaling) configuration on the same ranks: fresh engines + their own communicator, the same
-        episode loop, real gather and fences as the headline; shorter pre-warm."""
+    def secondary_leg(n_total, label):
+        """A further (strong-scaling) configuration on the same ranks: fresh engines + ONE communicator of their own, the
+        same episode loop, real gather and fences as the headline (shorter pre-warm), first as per-step launches, then --
+        same engines, same communicator -- as fused segments."""
         raw, n_local, fallback = make_engine(n_total, True)
-        r = measure(fab, raw, n_total, args.steps, args.warmup, args.episode_len, args.seed, fused=fused,
-                    overlap=not args.sync_gather, prewarm_s=0.15, min_timed_s=0.03)
-        name = "rollout_kernel (fused, one launch per episode segment)" if fused else raw.step_kernel_name()
+        kw = dict(overlap=not args.sync_gather, prewarm_s=0.15, min_timed_s=0.03)
+        r = measure(fab, raw, n_total, args.steps, args.warmup, args.episode_len, args.seed, fused=False, **kw)
+        f = measure(fab, raw, n_total, args.steps, args.warmup, args.episode_len, args.seed, fused=True, **kw)
+        name = raw.step_kernel_name()
         raw.close()
-        out = {"what": label, "scaling": "strong", "envs_total": n_total, "envs_on_rank0": n_local, "n_gpus": world,
-               "value": r["value"], "unit": "env-steps/s", "ms_per_step": r["ms_per_step"],
-               "ms_per_step_min": r["ms_per_step_min"], "ms_per_step_max": r["ms_per_step_max"],
-               "avg_kernel_us": r["step_us"], "kernel": name, "gather_us": r["gather_us"],
-               "gathers_in_timed_region": r["gathers_per_region"], "repeats": r["repeats"], "episode_len": r["episode_len"],
-               "collective": describe_collective(fallback), "gather_mode": gather_mode(fallback)}
-        if not fused:                                           # per-GPU fraction of the HBM peak while a step is on the device
-            out["frac_of_hbm_peak_per_gpu"] = bpe_actual * n_local / (r["step_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS
-            out["bytes_per_env_step"] = bpe_actual
-        return out
+        return {"what": label, "scaling": "strong", "envs_total": n_total, "envs_on_rank0": n_local, "n_gpus": world,
+                "value": r["value"], "unit": "env-steps/s", "ms_per_step": r["ms_per_step"],
+                "ms_per_step_min": r["ms_per_step_min"], "ms_per_step_max": r["ms_per_step_max"],
+                "avg_kernel_us": r["step_us"], "kernel": name, "gather_us": r["gather_us"],
+                "gathers_in_timed_region": r["gathers_per_region"], "repeats": r["repeats"], "episode_len": r["episode_len"],
+                "collective": describe_collective(fallback), "gather_mode": gather_mode(fallback),
+                # per-GPU fraction of the HBM peak while a step is on the device
+                "frac_of_hbm_peak_per_gpu": bpe_actual * n_local / (r["step_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                "bytes_per_env_step": bpe_actual,
+                "fused": {"value": f["value"], "ms_per_step": f["ms_per_step"], "avg_kernel_us": f["step_us"],
+                          "gather_us": f["gather_us"], "gathers_in_timed_region": f["gathers_per_region"],
+                          "kernel": "rollout_kernel (mt_rollout_fused: one launch per episode segment)",
+                          "repeats": f["repeats"]},
+                "fused_us_per_step": f["step_us"]}
 
     # ---- the headline: weak scaling (per-GPU work fixed) unless --envs-total ------------------------------------
     strong = args.envs_total > 0
@@ -711,11 +717,7 @@ def main():
                                ("config3", 4194304, "BASELINE.json configs[3]: 4 194 304 arms sharded over the GPUs")):
             if strong and nt == n_total:
                 continue                                        # that IS the headline of this invocation
-            leg = secondary_leg(nt, False, label)
-            f = secondary_leg(nt, True, label + ", mt_rollout_fused segments")
-            leg["fused"] = {k_: f[k_] for k_ in ("value", "ms_per_step", "avg_kernel_us", "gather_us", "gathers_in_timed_region",
-                                                 "kernel", "repeats")}
-            leg["fused_us_per_step"] = f["avg_kernel_us"]
+            leg = secondary_leg(nt, label)
             legs[key] = leg
         if rank == 0:
             out["secondary"] = legs
