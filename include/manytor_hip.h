@@ -226,7 +226,10 @@ MT_API int mt_set(mt_handle h, int field, const void* src, int64_t src_bytes);
 /* The episode index every env was given by the last full reset (finished-episode counts and return-ring slots are
  * relative to it): mt_reset / mt_reset_random set it; a checkpoint restore sets it back with this call. */
 MT_API int mt_set_episode_base(mt_handle h, uint32_t episode0);
-/* Raw resident buffer: pointer to row 0, number of rows, row stride in elements and element dtype. */
+/* Raw resident buffer: pointer to row 0, number of rows, row stride in elements and element dtype.  Writing through the
+ * pointer is the caller's business (order it with the handle's stream).  Asking for MT_F_GOALS tells the library that
+ * joint angles may change behind its back: from then on it never assumes them to be whole degrees (the table look-up
+ * the sampled-action kernels use for the pose a step starts from is replaced by the computed sines / cosines). */
 MT_API int mt_device_ptr(mt_handle h, int field, void** ptr, int64_t* rows, int64_t* ld, int* dtype);
 
 /* ---- multi-GPU: the one exchange of the path ---------------------------------------------------

@@ -781,7 +781,7 @@ int mt_reset(mt_handle h, const float* points, int layout, int is_device) {
   }
   h->args.major = 0;  // caller-supplied targets start episode 0 of every env
   h->args.episode0 = 0;
-  h->args.flags |= kFlagWholeGoals;  // every env is at the zero pose after this launch
+  if (!h->goals_exposed) h->args.flags |= kFlagWholeGoals;  // every env is at the zero pose after this launch
   MT_DISPATCH_D(h->D, launch_reset_d, h, h->args, 0);
   int rc = check_launch(h, "reset_kernel");
   if (rc) return rc;
@@ -798,7 +798,7 @@ static int reset_random_impl(mt_handle h, uint64_t seed, uint32_t episode, int m
   h->args.major = episode;
   if (mode == 1) {
     h->args.episode0 = episode;  // full reset: finished-episode counts restart from here
-    h->args.flags |= kFlagWholeGoals;  // every env is at the zero pose after this launch
+    if (!h->goals_exposed) h->args.flags |= kFlagWholeGoals;  // every env is at the zero pose after this launch
   }
   MT_DISPATCH_D(h->D, launch_reset_d, h, h->args, mode);
   int rc = check_launch(h, "reset_kernel");
@@ -1349,6 +1349,12 @@ int mt_device_ptr(mt_handle h, int field, void** ptr, int64_t* rows, int64_t* ld
   FieldInfo fi{};
   int rc = field_info(h, field, &fi);
   if (rc) return rc;
+  if (field == MT_F_GOALS) {
+    // the caller can now write joint angles behind the library's back at any time: the host's knowledge that every
+    // angle is a whole degree (kFlagWholeGoals: table look-ups for the pose a step starts from) ends here, for good
+    h->goals_exposed = true;
+    h->args.flags &= ~kFlagWholeGoals;
+  }
   *ptr = fi.ptr;
   if (rows) *rows = fi.rows;
   if (ld) *ld = (field == MT_F_DONE_BITS) ? h->ld / 64 : h->ld;

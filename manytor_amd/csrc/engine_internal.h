@@ -37,6 +37,7 @@ struct mt_engine {
   int split = 0;          // step_split_kernel<..., L>: one env over L = 2 or 4 lanes (0 = one env per lane)
   bool prefetch_forced = false;
   bool prefetch = false;  // step_kernel<..., PF = kPrefetch>: target loads requested ahead of the kinematics
+  bool goals_exposed = false;  // mt_device_ptr(MT_F_GOALS) was handed out: joint angles may change without the library knowing
   bool trig_steps = false;  // step kernels with TT: end-pose sines / cosines from the whole-degree table (static tables, sampled actions)
   int static_kind = 0;   // 0 runtime table, 1 Ref4Table, 2 Dh7Table
   mt_comm* comm = nullptr;

@@ -371,7 +371,7 @@ class StepEngine:
 
     @property
     def ld(self) -> int:
-        return self.device_ptr(L.F_GOALS)[2]
+        return self.device_ptr(L.F_REWARD)[2]      # any field: the row stride is the handle's (not F_GOALS: see mt_device_ptr)
 
     def device_tensor(self, field):
         """Zero-copy torch view of the resident SoA buffer: shape (rows, N) (or (N,) for single-row fields,

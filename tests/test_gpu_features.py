@@ -394,3 +394,30 @@ def test_environment_keeps_its_pose_mirror_when_the_kernel_rejects_an_action(m):
     tr = env.trajectory                                      # 1 seed row + 3 routes x 25 sub-steps
     assert tr.shape == (76, 3)
     np.testing.assert_allclose(tr[26:51], np.repeat(tr[25:26], 25, axis=0), atol=1e-5)   # the held step did not move
+
+
+def test_writing_goals_through_the_raw_pointer_is_seen_by_the_sampled_step(m):
+    """The sampled-action kernels look the sines / cosines of the pose a step STARTS from up in a whole-degree table while
+    the host knows every angle to be a whole degree.  A caller who takes the raw MT_F_GOALS pointer (torch view) can write
+    fractional angles behind the library's back: handing the pointer out must end that assumption -- the next sampled
+    step has to start from exactly the pose that was written."""
+    import torch
+    from oracle import c_oracle
+    n, k = 4096, 2
+    e = m.StepEngine(n, k, debug_zmin=True)
+    e.reset_random(5, 0)
+    e.step_random(5, 0)                                       # whole-degree poses, table path
+    g = e.device_tensor(m.lib.F_GOALS)                        # (D, N) view of the resident rows
+    frac = torch.rand(g.shape, device=g.device) * 300.0 - 150.0
+    e.sync()
+    g.copy_(frac)
+    torch.cuda.synchronize()
+    prev = e.goals().astype(np.float64)
+    np.testing.assert_array_equal(prev, frac.T.cpu().numpy().astype(np.float64))
+    e.step_random(5, 1)
+    ora = c_oracle.COracle(n, k, threads=4)
+    ora.reset(e.points().astype(np.float64))
+    ora.goals[:] = prev
+    ora.step(e.goals().astype(np.float64))
+    assert np.abs(e.zmin() - ora.zmin).max() <= 1e-4          # the route really started at the fractional pose
+    assert np.abs(e.ee() - ora.joints_coordinates[:, -1]).max() <= 1e-4

@@ -37,10 +37,10 @@ def step_us(n, pad=None, steps=300, reps=3):
         e.timer_start()
         e.rollout(50, 1, 0)
         out.append(e.timer_stop() * 1e3 / 50)
-    ptr = e.device_ptr(m.lib.F_GOALS)[0]
+    ptr = e.device_ptr(m.lib.F_REWARD)[0]
     ld = e.ld
     e.close()
-    return {"us": [round(v, 2) for v in out], "arena_goals_ptr": hex(ptr), "ld": ld}
+    return {"us": [round(v, 2) for v in out], "arena_reward_ptr": hex(ptr), "ld": ld}
 
 
 def copy_gbs(nbytes=1 << 30):
