@@ -378,8 +378,8 @@ void launch_rollout_split_t(mt_handle h, const RolloutArgs& r) {
 
 template <class Tbl>
 void launch_rollout_t(mt_handle h, const RolloutArgs& r) {
-  if (h->split == 4) return launch_rollout_split_t<Tbl, 4>(h, r);
-  if (h->split == 2) return launch_rollout_split_t<Tbl, 2>(h, r);
+  if (h->rollout_split == 4) return launch_rollout_split_t<Tbl, 4>(h, r);
+  if (h->rollout_split == 2) return launch_rollout_split_t<Tbl, 2>(h, r);
   // 21.5 KB at K = 7, 96 KB at K = 32 (of 160 KB), + 3.6 KB for the action sin / cos table of the compile-time tables
   const size_t lds = (size_t)3 * h->K * kBlock * sizeof(float) + (ActionTrigTable<Tbl>::value ? kTrigEntries * sizeof(SinCos) : 0);
   if (lds > 65536)  // above the default dynamic-LDS limit the kernel has to be told
@@ -539,9 +539,13 @@ int mt_create(mt_handle* out, const mt_config* cfg) {
   // MT_SPLIT = 0/2/4 and MT_PREFETCH = 0/1 override the choice for experiments and tests.
   h->split = cfg->n_envs <= 32768 ? 4 : (cfg->n_envs <= 65536 ? 2 : 0);
   h->prefetch = cfg->n_envs <= 131072;  // widened for the reference arm once the table is known (below)
+  // The fused rollout keeps two lanes per env up to 131 072 arms (tools/fused_split_sweep.py, round 3: 3.60 against 4.50 us
+  // per step at 98 304 arms, 4.37 against 4.50 at 131 072; one env per lane wins from 196 608 on).
+  h->rollout_split = cfg->n_envs <= 32768 ? 4 : (cfg->n_envs <= 131072 ? 2 : 0);
   if (const char* env = std::getenv("MT_SPLIT")) {
     const int v = std::atoi(env);
     h->split = (v == 2 || v == 4) ? v : 0;
+    h->rollout_split = h->split;
   }
   // The reset's target draw is spread over 4 lanes per env while the batch is small enough for the kernel to be one
   // wave per SIMD walking its Philox blocks serially: 11.2 -> 6.9 us at 16 384 arms, 12.1 -> 10.0 at 65 536, a tie at
@@ -644,6 +648,7 @@ int mt_create(mt_handle* out, const mt_config* cfg) {
   if (h->custom_frames) {
     h->lds_table = false;
     h->split = 0;
+    h->rollout_split = 0;
     h->prefetch = false;
   }
   h->static_kind = ((cfg->flags & (MT_FLAG_NO_SPECIALIZE | MT_FLAG_DH_IN_LDS)) || h->custom_frames) ? 0 : match_static(a.dh, h->D);

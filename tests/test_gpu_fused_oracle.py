@@ -135,13 +135,15 @@ def test_fused_rollout_every_env_against_the_c_oracle_full_size(m, table_name, T
 @pytest.mark.parametrize("n,table_name,auto_reset,tol,kernel,floor", [
     (65536, "ref", False, 8.0, "L=2", 0.9401),      # BASELINE.json configs[1]: rollout_split_kernel<Ref4Table, 2>; measured 0.9601
     (65536, "dh7", True, 45.0, "L=2", 0.9649),      # 0.9849
-    (131072, "ref", True, 20.0, "pf=8", 0.9532),    # the per-GPU shard of 1 M arms over 8 GPUs: rollout_kernel, one env per lane; 0.9732
+    (131072, "ref", True, 20.0, "pf=8", 0.9532),    # the per-GPU shard of 1 M arms over 8 GPUs: rollout_split_kernel<.., 2> (step kernel: one env per lane); 0.9732
     (131072, "dh7", False, 8.0, "pf=8", 0.9530),    # 0.9730
     (32768, "ref", True, 20.0, "L=4", 0.9542),      # rollout_split_kernel<.., 4>; 0.9742
 ])
 def test_fused_rollout_every_env_against_the_c_oracle_at_each_dispatch_regime(m, n, table_name, auto_reset, tol, kernel, floor):
     probe = m.StepEngine(n, 7, dh_table=_tables(m)[table_name][0], radius=_tables(m)[table_name][1])
-    assert kernel in probe.step_kernel_name(), probe.step_kernel_name()    # the split / one-lane choice is shared with the rollout
+    # the regime, named by its step kernel (the fused rollout spreads an env over 4 lanes up to 32 768 arms and over 2 up to
+    # 131 072; bit-identical to the one-lane kernel either way: test_rollout_kernel_variants_are_bit_identical)
+    assert kernel in probe.step_kernel_name(), probe.step_kernel_name()
     probe.close()
     stats = run_fused_against_oracle(m, n, 7, table_name, 25, auto_reset, tol, seed=0xD15 + n, min_clean=floor)
     if auto_reset:
