@@ -554,10 +554,12 @@ int mt_create(mt_handle* out, const mt_config* cfg) {
   if (const char* env = std::getenv("MT_RESET_SPLIT")) h->reset_split = std::atoi(env) != 0;
   if (const char* env = std::getenv("MT_GRAPH")) h->graph_mode = std::atoi(env) != 0 ? 1 : 0;
   // mt_rollout as independent chains of launches on separate streams (engine_internal.h): MT_CHAINS = 1..4 overrides
-  // Two chains from 196 608 to 3 M envs (tools/chain_sweep.py --steady, profiles/r03_variants.md section 2: 10.5 -> 8.7 us per
-  // step at 262 144 envs, 21.5 -> 19.8 at 524 288, 39.9 -> 36.3 at 1 M, 74.6 -> 69.0 at 2 M; nothing at 4 M, where the
-  // launches are long and purely HBM-bound; below, the fork / join of every call costs more than the overlap returns).
-  h->chains = (cfg->n_envs >= 196608 && cfg->n_envs <= 3145728) ? 2 : 1;
+  // Two chains from 163 840 to 3 M envs (tools/chain_sweep.py --steady, tools/chain_variant_probe.py, profiles/r03_variants.md
+  // section 2: 8.45 -> 7.95 us per step at 163 840 envs, 10.5 -> 8.7 at 262 144, 21.5 -> 19.8 at 524 288, 39.9 -> 36.3 at 1 M,
+  // 74.6 -> 69.0 at 2 M; nothing at 4 M, where the launches are long and purely HBM-bound; at 131 072 envs = exactly two
+  // blocks per CU one launch is best (7.14 against 7.3-7.7), and below that the fork / join of every call costs more
+  // than the overlap returns, except at sizes that fill the CUs unevenly (98 304 envs: 7.1 -> 6.5) -- not special-cased).
+  h->chains = (cfg->n_envs >= 163840 && cfg->n_envs <= 3145728) ? 2 : 1;
   if (const char* env = std::getenv("MT_CHAINS")) h->chains = std::max(1, std::min((int)mt_engine::kMaxChains, std::atoi(env)));
   if (cfg->n_envs < 2 * 256) h->chains = 1;
   h->prefetch_forced = false;

@@ -1,0 +1,20 @@
+import os, sys, time, json
+sys.path.insert(0, os.getcwd())
+import manytor_amd as m
+def steady(n, env, episodes=12):
+    for k in ("MT_CHAINS","MT_GRAPH","MT_SPLIT","MT_PREFETCH"): os.environ.pop(k, None)
+    os.environ.update(env)
+    e = m.StepEngine(n, 7)
+    t0 = time.perf_counter(); ep = 0
+    while time.perf_counter() - t0 < 0.15:
+        e.reset_random(1, ep); e.rollout(50, 1, 0); ep += 1; e.sync()
+    e.timer_start()
+    for r in range(episodes):
+        e.reset_random(1, r); e.rollout(50, 1, 0)
+    ms = e.timer_stop(); name = e.step_kernel_name(); e.close()
+    return round(ms * 1e3 / (episodes * 50), 3), name
+for n in (98304, 131072, 163840):
+    for env in ({}, {"MT_CHAINS":"2","MT_GRAPH":"1"}, {"MT_CHAINS":"2","MT_GRAPH":"1","MT_SPLIT":"0"}, {"MT_CHAINS":"2","MT_GRAPH":"0","MT_SPLIT":"0"},
+                {"MT_CHAINS":"2","MT_GRAPH":"1","MT_SPLIT":"0","MT_PREFETCH":"0"}, {"MT_CHAINS":"3","MT_GRAPH":"1","MT_SPLIT":"0"}):
+        a = steady(n, env); b = steady(n, env)
+        print(n, env, a[0], b[0], a[1][-60:], flush=True)

@@ -11,4 +11,5 @@ run fetch FETCH_SIZE
 run write WRITE_SIZE
 run sq SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY
 run grbm GRBM_GUI_ACTIVE
+run tcc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum
 python3 tools/pmc_summary.py "$out"
