@@ -26,6 +26,7 @@ import argparse
 import json
 import math
 import os
+import re
 import sys
 import time
 
@@ -625,6 +626,9 @@ def main():
     out = None
     if rank == 0:
         step_s = r["step_us"] * 1e-6                            # device time of one step of this rank's envs (HIP events)
+        # mt_rollout may run a step as several concurrent launches on env ranges (the kernel name says so)
+        mm = re.search(r"\[mt_rollout: (\d+) chains of (\d+) envs", kernel_name)
+        chains, envs_per_launch = (int(mm.group(1)), int(mm.group(2))) if (mm and not args.fused) else (1, n_local)
         achieved = bpe_actual * n_local / step_s / 1e9
         achieved_model = bpe * n_local / step_s / 1e9
         trig = 2 if args.hw_trig else (1 if args.direct_trig else 0)
@@ -661,7 +665,9 @@ def main():
                                   "profiles/ (traffic.json); not re-measured in this run",
                 "kernel": (f"rollout_kernel<{table_name}> ({L} steps per launch; us per step quoted)" if args.fused else
                            kernel_name + " (action drawn in-kernel)"),
-                "bytes_per_env_step": bpe_actual, "avg_kernel_us": r["step_us"], "kernel_launches_timed": r["launches"],
+                "bytes_per_env_step": bpe_actual, "avg_kernel_us": r["step_us"], "steps_timed": r["launches"],
+                "launches_per_step": chains, "envs_per_launch": envs_per_launch,
+                "bytes_per_launch": bpe_actual * envs_per_launch, "bytes_per_step": bpe_actual * n_local,
                 "bytes_per_env_step_survey_model": bpe, "achieved_survey_model": achieved_model,
                 "frac_survey_model": achieved_model / HBM_PEAK_GBS,
                 "regime": ("HBM + Infinity Cache: the %.0f MB a step touches are about the size of the 256 MiB MALL, so part "
@@ -670,9 +676,12 @@ def main():
                 "note": "achieved / frac use the bytes the timed kernel really moves per env-step (SURVEY 8(d)'s 12 D + 24 K + "
                         "33 minus the 4 D-byte action read it does not do: the action is drawn in registers and IS the new "
                         "goals); *_survey_model are the same with SURVEY's own figure.  avg_kernel_us = device time of ONE "
-                        "STEP of this rank's envs by HIP events around the step launches; when mt_rollout runs the step as "
-                        "two concurrent launches on two streams (config.kernel says so) rocprofv3's per-launch average is "
-                        "about twice this divided by the overlap -- profiles/ holds the per-step union from the same trace",
+                        "STEP of this rank's envs (bytes_per_step) by HIP events around the step launches, fork and join of "
+                        "the chains included.  With launches_per_step = 2 a step is two CONCURRENT launches of "
+                        "envs_per_launch envs on two streams: rocprofv3's per-launch average (34.7 us for 524 288 envs, "
+                        "profiles/r03_kernel_stats_by_grid.csv) is then the duration of each of two overlapping kernels, "
+                        "not half a step; the union of their intervals per step (35.2 us, same file, last line) is the "
+                        "figure that corresponds to avg_kernel_us",
             },
         }
         if world == 1:

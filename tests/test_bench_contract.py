@@ -39,6 +39,8 @@ def test_bench_prints_one_contract_line():
     assert r["achieved"] == pytest.approx(233 * 262144 / (r["avg_kernel_us"] * 1e-6) / 1e9, rel=1e-6)
     assert r["frac_survey_model"] == pytest.approx(r["frac"] * 249 / 233, rel=1e-6)
     assert r["avg_kernel_us"] * 1e-3 <= d["ms_per_step"]                 # the step's device time fits inside the wall-clock step
+    assert r["launches_per_step"] == 2 and r["envs_per_launch"] == 131072 and "2 chains of 131072 envs" in r["kernel"]
+    assert r["bytes_per_step"] == 233 * 262144 and r["bytes_per_launch"] * r["launches_per_step"] == r["bytes_per_step"]
     c = d["cpu_baseline"]
     for key in ("value", "unit", "cores", "kind", "sample", "numpy_multiprocess_value", "numpy_multiprocess_cores"):
         assert key in c, key
