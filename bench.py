@@ -12,11 +12,16 @@ resident in HBM when the timed region starts.  Every `episode_len` steps the ret
 over the ranks (mt_gather_returns: RCCL all-gather straight from the arena, the only collective) and
 all envs are reset (test_multi.py:32-34).
 
-Timing protocol (robust to short --steps): a time-based pre-warm brings the GPU to its steady clock,
-then W untimed warm-up steps, then the region of EXACTLY K steps -- bracketed by barrier +
-torch.cuda.synchronize() on both sides, max over ranks -- is run `repeats` times; `ms_per_step` /
-`value` come from the MEDIAN region (min / max beside it).  Kernel time is measured with HIP events on
-the engine's stream around the step launches of every region.
+Timing protocol (robust to short --steps; `measure()`): a time-based pre-warm brings the GPU to its steady clock, then W
+untimed warm-up steps, the running episode is ended so that a region starts an episode, then the region of EXACTLY K steps
+-- bracketed by barrier + torch.cuda.synchronize() on both sides, max over ranks -- is run `repeats` times; `ms_per_step` /
+`value` come from the MEDIAN region (min / max beside it).  The device time of a step is measured with HIP events on the
+engine's stream around the step launches of every region (mt_rollout may run a step as two concurrent launches on two
+streams, forked from and joined to that stream inside the laps; `roofline` says so).
+
+With N > 1 the same invocation then measures, on the same ranks, the two strong-scaling configurations BASELINE.json's
+north_star names -- `secondary.strong_1m` (1 048 576 arms sharded) and `secondary.config3` (4 194 304 arms sharded), each as
+per-step launches and as fused segments -- so that the driver's one command per N captures them.
 
 Prints ONE JSON line on rank 0 (contract: see the task brief / DESIGN.md section "Measurement").
 """

@@ -671,10 +671,10 @@ constexpr int kPrefetch = 8;
 //   TT     : sampled actions are whole degrees, and so is the pose they leave behind: with a compile-time table (whole-
 //            degree joint offsets) the sines / cosines of BOTH end poses of the route come out of the 450-entry
 //            whole-degree table (fill_trig_table_kernel), staged into LDS per block, instead of 2 (JN - 1) + 1 range
-//            reductions and polynomials per env -- 13 % of the kernel's instructions for the reference arm, which is what
-//            matters where the launch is VALU-issue-bound (the 131 072 .. 262 144-arm shards of a strong-scaled job).
-//            Whole batch only (threads past the end of the batch run up to the barrier: their loads stay inside the
-//            rows, which are ld >= round_up(n, 256) long); same bits as the computed values.
+//            reductions and polynomials per env: 1 277 -> 1 153 instructions per wave for the reference arm, 1.5-6 % time
+//            (most where an env is spread over lanes and the end poses are replicated; profiles/r03_variants.md section 3).
+//            Whole batch or a 256-aligned range of it only (threads past the end run up to the barrier: their loads stay
+//            inside the rows, which are ld >= round_up(n, 256) long); same bits as the computed values.
 template <class Tbl, bool SAMPLE, int TRIG, bool LDS, int PF = 0, bool TT = false>
 __global__ __launch_bounds__(kBlock, (PF ? 1 : step_min_waves<Tbl, TRIG>())) void step_kernel(const StepArgs a) {
   constexpr int D = Tbl::D;

@@ -25,6 +25,7 @@ ap.add_argument("--seed", type=int, default=0)
 args = ap.parse_args()
 rng = np.random.RandomState(args.seed)
 deadline = time.time() + 60 * args.minutes
+last_note = time.time()
 cases = guarded = compared = 0
 while time.time() < deadline:
     dof = int(rng.randint(2, 9))
@@ -61,6 +62,9 @@ while time.time() < deadline:
             a = rng.randint(-720, 720, size=(n, dof)).astype(np.float64)                                   # far outside [-180,180)
         ls.step(a)
     cases += 1
+    if time.time() - last_note > 45:                 # a long silent run looks hung to the GPU box's watchdog
+        print(f"... {cases} configurations so far", flush=True)
+        last_note = time.time()
     guarded += ls.guarded
     compared += ls.compared
     ls.eng.close()

@@ -33,6 +33,7 @@ ap.add_argument("--seed", type=int, default=0)
 args = ap.parse_args()
 rng = np.random.RandomState(args.seed)
 deadline = time.time() + 60 * args.minutes
+last_note = time.time()
 cases = 0
 worst_z = worst_ee = 0.0
 while time.time() < deadline:
@@ -101,6 +102,9 @@ while time.time() < deadline:
     assert ez <= gate and ee <= gate, (ez, ee, gate, knobs, n, k, dof, substeps)
     worst_z, worst_ee = max(worst_z, float(ez)), max(worst_ee, float(ee))
     cases += 1
+    if time.time() - last_note > 45:                 # a long silent run looks hung to the GPU box's watchdog
+        print(f"... {cases} configurations so far", flush=True)
+        last_note = time.time()
 for key in KNOBS:
     os.environ.pop(key, None)
 print(f"fuzz_rollout ok: {cases} random configurations x (plain schedule, random schedule) bit-identical on {len(FIELDS)} fields; "
