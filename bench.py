@@ -44,6 +44,7 @@ METRIC = "env-steps/sec (whole node), 1M parallel 4-DoF arms, random actions"
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
 MIN_TIMED_S = 0.25           # the repeated timed regions together cover at least this much GPU work (5..300 regions)
 PREWARM_S = 0.3
+F_LAST_RETURN = 12           # mt_field MT_F_LAST_RETURN (include/manytor_hip.h): the return an env had when it was last reset
 
 
 def algorithmic_bytes_per_env_step(dof, k):
@@ -208,9 +209,11 @@ class EpisodeLoop:
     """The benchmark's control flow, the shape of test_multi.py:17-34: `episode_len` random-action steps, then gather
     the returns of all ranks and reset every env.  `engine` needs rollout / rollout_fused / reset_random /
     gather_begin / gather_wait / gather_returns / lap_begin / lap_end (manytor_amd.StepEngine; a stand-in in the CPU
-    rehearsal test).  With `overlap` (default) the gather is begun on the engine's side stream from a snapshot of the
-    returns and the next episode's reset and steps run beside it; its result is the previous episode's, as a learner
-    would consume it, in one of two alternating buffers."""
+    rehearsal test).  With `overlap` (default) the gather runs on the engine's side stream while the next episode's steps
+    run beside it; its result is the previous episode's, as a learner would consume it, in one of two alternating
+    buffers."""
+
+    reset_first = False         # experiment switch (--reset-before-gather), see _episode_end
 
     def __init__(self, engine, seed, episode_len, fused=False, overlap=True):
         self.eng, self.seed, self.L, self.fused, self.overlap = engine, seed, int(episode_len), fused, overlap
@@ -231,19 +234,32 @@ class EpisodeLoop:
             self._episode_end(False)
 
     def _episode_end(self, time_kernels):
+        """test_multi.py:32-34: read every env's return, then reset every env.  Overlapped form: the returns are
+        snapshotted (per chain while mt_rollout's chains are forked, each range behind its own last step), the exchange
+        runs on the engine's side stream, and the reset -- per chain as well -- and the next episode run beside it.
+        `reset_first` is the measured alternative: reset first (it stores each env's finished return in
+        MT_F_LAST_RETURN), then gather that row in place, no snapshot copy (tools/ab_episode_end.sh: a tie)."""
+        self.episode += 1
+        if self.reset_first:
+            self.eng.reset_random(self.seed, self.episode)
+            if self.overlap:
+                b = self.gathers % 2
+                self._bufs[b] = self.gathered = self.eng.gather_begin(self._bufs[b], field=F_LAST_RETURN, snapshot=False)
+            else:
+                self.gathered = self.eng.gather_returns(self.gathered, field=F_LAST_RETURN)
+            self.gathers += 1
+            return
         if self.overlap:
             self.eng.gather_wait()                   # stream order only: the previous exchange finished long ago
             b = self.gathers % 2
             self._bufs[b] = self.gathered = self.eng.gather_begin(self._bufs[b])
-            self.gathers += 1
         else:
             if time_kernels:
                 self.eng.lap_begin("gather")
             self.gathered = self.eng.gather_returns(self.gathered)     # RCCL all-gather (device copy at N = 1)
             if time_kernels:
                 self.eng.lap_end("gather")
-            self.gathers += 1
-        self.episode += 1
+        self.gathers += 1
         self.eng.reset_random(self.seed, self.episode)
 
     def run(self, count, time_kernels=False):
@@ -471,6 +487,9 @@ def main():
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x5EED)
     ap.add_argument("--sync-gather", action="store_true",
                     help="run the return gather in line on the engine's stream instead of overlapped on its side stream")
+    ap.add_argument("--reset-before-gather", action="store_true",
+                    help="experiment: at an episode end reset first, then gather MT_F_LAST_RETURN in place (no snapshot copy) "
+                         "instead of snapshot + gather, then reset")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
@@ -510,6 +529,7 @@ def main():
     import manytor_amd as m
     from manytor_amd import distributed as D
 
+    EpisodeLoop.reset_first = args.reset_before_gather
     rank, local_rank, world = D.env_from_torchrun()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
@@ -588,8 +608,12 @@ def main():
     def gather_mode(fallback):
         if fallback or args.rehearsal:
             return "in line (the stand-in gathers do not overlap anything)"
+        if args.reset_before_gather and not args.sync_gather:
+            return ("overlapped: the reset stores the finished returns (MT_F_LAST_RETURN), the exchange reads them in place on "
+                    "the engine's side stream (mt_gather_returns_begin_inplace) beside the next episode's steps")
         return ("in line on the engine's stream" if args.sync_gather else
-                "overlapped: snapshot + exchange on the engine's side stream (mt_gather_returns_begin)")
+                "overlapped: snapshot (per chain) + exchange on the engine's side stream (mt_gather_returns_begin), beside "
+                "the reset and the next episode's steps")
 
     def secondary_leg(n_total, label):
         """A further (strong-scaling) configuration on the same ranks: fresh engines + ONE communicator of their own, the

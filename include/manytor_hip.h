@@ -200,10 +200,13 @@ MT_API int mt_step_random(mt_handle h, uint64_t seed, uint32_t step_idx);
  * inner loop of test_multi.py:19-21).  On small batches (<= 131 072 envs) the launches are replayed from a HIP graph
  * that the handle captures once per segment length: the same kernels, the same results, less time per kernel boundary.
  * On large batches (163 840 .. 3 M envs) the call runs as TWO independent chains of launches -- the two halves of the env
- * range (256-aligned) on two streams, forked from the handle's stream and joined back to it before the call returns to
- * stream order: a step of env i depends only on env i, so the results are bit-identical, and one half's kernel boundary
- * is hidden behind the other half's kernel (-10 % per step at 1 M envs).  Work queued on the handle's stream afterwards
- * sees the completed rollout as before. */
+ * range (256-aligned) on two streams forked from the handle's stream: a step of env i depends only on env i, so the
+ * results are bit-identical, and one half's kernel boundary is hidden behind the other half's kernel (-10 % per step at
+ * 1 M envs).  On the handle's own stream the chains stay forked when the call returns: the next mt_rollout continues them,
+ * mt_reset_random resets each half behind its own last step, mt_gather_returns_begin snapshots each half on its chain;
+ * every other call -- mt_sync, getters, setters, mt_step, mt_reset_done, timers' begin ... -- folds them back into the
+ * handle's stream first, so "mt_sync before foreign reads" means what it did.  On a caller's stream (mt_set_stream) the
+ * chains are joined before the call returns: work queued on that stream afterwards sees the completed rollout. */
 MT_API int mt_rollout(mt_handle h, int n_steps, uint64_t seed, uint32_t step_idx0);
 /* The same n_steps steps in ONE launch: joint angles, alive mask and return stay in registers and the targets
  * in LDS between steps, so a step only writes its outputs (obs, reward, done, end effector; MT_F_* hold the last
@@ -261,6 +264,11 @@ MT_API int mt_gather_returns(mt_handle h, int field, int row, float* dst, int64_
  * also waits for a begun gather. */
 MT_API int mt_gather_returns_begin(mt_handle h, int field, int row, float* dst, int64_t dst_elems);
 MT_API int mt_gather_returns_wait(mt_handle h, int host_wait, float* elapsed_ms);
+/* The same without the snapshot: the exchange on the side stream reads the arena row itself, so nothing is copied on the
+ * handle's stream.  Meant for MT_F_LAST_RETURN right after the reset that ended an episode (the reset stores every env's
+ * finished return there): that row is written by resets only, and the library orders every later reset / re-arm of its
+ * own behind the exchange.  For any other row the caller must not let it change before mt_gather_returns_wait. */
+MT_API int mt_gather_returns_begin_inplace(mt_handle h, int field, int row, float* dst, int64_t dst_elems);
 /* Total number of envs over all ranks of the communicator (n_envs without one). */
 MT_API int mt_comm_total_envs(mt_handle h, int64_t* total);
 /* Summary of a return row over ALL ranks without moving the row (what a learner logs per episode):

@@ -117,6 +117,7 @@ PROTOTYPES = {
     "mt_gather_returns": (C.c_int, [_HANDLE, C.c_int, C.c_int, C.c_void_p, C.c_int64]),
     "mt_gather_returns_begin": (C.c_int, [_HANDLE, C.c_int, C.c_int, C.c_void_p, C.c_int64]),
     "mt_gather_returns_wait": (C.c_int, [_HANDLE, C.c_int, C.POINTER(C.c_float)]),
+    "mt_gather_returns_begin_inplace": (C.c_int, [_HANDLE, C.c_int, C.c_int, C.c_void_p, C.c_int64]),
     "mt_comm_total_envs": (C.c_int, [_HANDLE, C.POINTER(C.c_int64)]),
     "mt_reduce_returns": (C.c_int, [_HANDLE, C.c_int, C.c_int, C.c_void_p]),
     "mt_timer_start": (C.c_int, [_HANDLE]),

@@ -6,6 +6,7 @@
 // librccl.so is resolved at run time with dlopen, so the library itself links only libamdhip64.
 #include <dlfcn.h>
 
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -148,7 +149,7 @@ int mt_comm_init(mt_handle h, const void* unique_id, int rank, int world_size) {
   if (h->comm) return fail(h, MT_ERR_STATE, "mt_comm_init: the handle already has a communicator");
   Rccl* r = rccl();
   if (!r) return fail(h, MT_ERR_UNSUPPORTED, "RCCL is not available: " + g_rccl.error);
-  MT_ON_DEVICE(h, h->cfg.device);
+  MT_ENTER(h);
   mt_comm* c = new (std::nothrow) mt_comm();
   if (!c) return fail(h, MT_ERR_ALLOC, "out of host memory");
   c->rank = rank;
@@ -208,7 +209,7 @@ int mt_comm_init(mt_handle h, const void* unique_id, int rank, int world_size) {
 
 int mt_comm_destroy(mt_handle h) {
   MT_REQUIRE(nullptr, h != nullptr, "handle is NULL");
-  MT_ON_DEVICE(h, h->cfg.device);
+  MT_ENTER(h);
   MT_HIP(h, hipStreamSynchronize(h->stream));
   if (h->gather_pending) {
     MT_HIP(h, hipStreamSynchronize(h->side_stream));
@@ -327,7 +328,7 @@ int mt_gather_returns(mt_handle h, int field, int row, float* dst, int64_t dst_e
   int rc;
   const float* src = gather_source(h, field, row, &rc);
   if (!src) return rc;
-  MT_ON_DEVICE(h, h->cfg.device);
+  MT_ENTER(h);
   rc = order_behind_pending_gather(h, h->stream);  // the two forms share the communicator and its staging buffer
   if (rc) return rc;
   return gather_on_stream(h, src, dst, dst_elems, h->stream);
@@ -339,7 +340,7 @@ int mt_reduce_returns(mt_handle h, int field, int row, mt_return_stats* out) {
   int rc;
   const float* src = gather_source(h, field, row, &rc);
   if (!src) return rc;
-  MT_ON_DEVICE(h, h->cfg.device);
+  MT_ENTER(h);
   mt_comm* c = h->comm;
   const int world = (c && c->world > 1) ? c->world : 1;
   // device scratch: [kReduceBlocks] block partials, then [world + 1] per-rank records (slot `world` = this rank's)
@@ -406,13 +407,21 @@ int mt_reduce_returns(mt_handle h, int field, int row, mt_return_stats* out) {
   return body();
 }
 
-int mt_gather_returns_begin(mt_handle h, int field, int row, float* dst, int64_t dst_elems) {
+static int gather_begin_impl(mt_handle h, int field, int row, float* dst, int64_t dst_elems, bool inplace) {
   MT_REQUIRE(nullptr, h != nullptr, "handle is NULL");
   MT_REQUIRE(h, dst != nullptr, "dst is NULL");
   int rc;
   const float* src = gather_source(h, field, row, &rc);
   if (!src) return rc;
+  // A snapshot gather begun while mt_rollout's chains are forked takes the snapshot PER CHAIN: every chain copies its own
+  // env range behind its own last step, the exchange waits for all of them, and the chains stay forked -- a per-chain
+  // reset queued next then runs beside the exchange instead of behind a join.  Everything else joins first.
+  const bool per_chain = !inplace && h->forked && h->lazy_chains && h->stream == h->own_stream;
   MT_ON_DEVICE(h, h->cfg.device);
+  if (!per_chain) {
+    rc = mt::join_chains(h);
+    if (rc) return rc;
+  }
   if (!h->snap) {  // first use: the side stream, its events, and the snapshot row (`snap` is set last: all or nothing)
     hipError_t e = hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_snap, hipEventDisableTiming);
@@ -426,25 +435,57 @@ int mt_gather_returns_begin(mt_handle h, int field, int row, float* dst, int64_t
                   std::string("mt_gather_returns_begin: set-up of the side stream failed: ") + hipGetErrorString(e));
     }
   }
-  // the snapshot may only be overwritten once the previous exchange has read it
+  // the snapshot (and the communicator's staging) may only be reused once the previous exchange has finished
   rc = order_behind_pending_gather(h, h->stream);
   if (rc) return rc;
-  MT_HIP(h, hipMemcpyAsync(h->snap, src, sizeof(float) * (size_t)h->n, hipMemcpyDeviceToDevice, h->stream));
+  if (per_chain) {
+    const int64_t per = (h->n + h->chains - 1) / h->chains, span = (per + 255) / 256 * 256;  // engine.hip: chain_span
+    for (int c = 0; c < h->chains; ++c) {
+      const int64_t off = (int64_t)c * span;
+      if (off >= h->n) continue;
+      hipStream_t sc = c == 0 ? h->stream : h->chain_streams[c];
+      if (c > 0) {
+        rc = order_behind_pending_gather(h, sc);
+        if (rc) return rc;
+      }
+      const int64_t cnt = std::min(span, h->n - off);
+      MT_HIP(h, hipMemcpyAsync(h->snap + off, src + off, sizeof(float) * (size_t)cnt, hipMemcpyDeviceToDevice, sc));
+      if (c > 0) {
+        if (!h->ev_join[c]) return fail(h, MT_ERR_STATE, "mt_gather_returns_begin: chain without its event");
+        // (ev_join[c] is free while the chains are forked: a join records it afresh)
+        MT_HIP(h, hipEventRecord(h->ev_join[c], sc));
+        MT_HIP(h, hipStreamWaitEvent(h->side_stream, h->ev_join[c], 0));
+      }
+    }
+    src = h->snap;
+  } else if (!inplace) {
+    MT_HIP(h, hipMemcpyAsync(h->snap, src, sizeof(float) * (size_t)h->n, hipMemcpyDeviceToDevice, h->stream));
+    src = h->snap;
+  }
   MT_HIP(h, hipEventRecord(h->ev_snap, h->stream));
   MT_HIP(h, hipStreamWaitEvent(h->side_stream, h->ev_snap, 0));
   MT_HIP(h, hipEventRecord(h->ev_g0, h->side_stream));
-  rc = gather_on_stream(h, h->snap, dst, dst_elems, h->side_stream);
+  rc = gather_on_stream(h, src, dst, dst_elems, h->side_stream);
   if (rc) return rc;
   MT_HIP(h, hipEventRecord(h->ev_g1, h->side_stream));
   h->gather_pending = true;
+  h->gather_inplace = inplace;
   return MT_OK;
+}
+
+int mt_gather_returns_begin(mt_handle h, int field, int row, float* dst, int64_t dst_elems) {
+  return gather_begin_impl(h, field, row, dst, dst_elems, false);
+}
+
+int mt_gather_returns_begin_inplace(mt_handle h, int field, int row, float* dst, int64_t dst_elems) {
+  return gather_begin_impl(h, field, row, dst, dst_elems, true);
 }
 
 int mt_gather_returns_wait(mt_handle h, int host_wait, float* elapsed_ms) {
   MT_REQUIRE(nullptr, h != nullptr, "handle is NULL");
   if (elapsed_ms) *elapsed_ms = host_wait ? h->last_gather_ms : 0.f;  // nothing pending: the last completed exchange
   if (!h->gather_pending) return MT_OK;
-  MT_ON_DEVICE(h, h->cfg.device);
+  MT_ON_DEVICE(h, h->cfg.device);  // no join: only the handle's own stream is ordered behind the exchange
   MT_HIP(h, hipStreamWaitEvent(h->stream, h->ev_g1, 0));
   if (host_wait) {
     MT_HIP(h, hipEventSynchronize(h->ev_g1));

@@ -32,6 +32,17 @@ int fail(mt_handle h, int code, const std::string& msg) {
     g_last_error = msg;
   return code;
 }
+
+int join_chains(mt_handle h) {
+  if (!h->forked) return MT_OK;
+  h->forked = false;
+  for (int c = 1; c < mt_engine::kMaxChains; ++c) {
+    if (!h->chain_streams[c] || !h->ev_join[c]) continue;
+    MT_HIP(h, hipEventRecord(h->ev_join[c], h->chain_streams[c]));
+    MT_HIP(h, hipStreamWaitEvent(h->stream, h->ev_join[c], 0));
+  }
+  return MT_OK;
+}
 }  // namespace mt
 
 namespace {
@@ -252,30 +263,25 @@ void launch_chain(mt_handle h, const StepArgs& a0, uint32_t major0, int T, int c
   h->prefetch = keep_pf;
 }
 
-// Fork the chain streams from `root` (the stream the handle's work is ordered on), run body(c) with h->stream = chain
-// c's stream (chain 0: root itself), join them back into `root`.
-template <class Body>
-int fork_join_chains(mt_handle h, hipStream_t root, int chains, Body&& body) {
+// Chain c's stream (chain 0 runs on the handle's own stream).
+hipStream_t chain_stream(mt_handle h, int c) { return c == 0 ? h->stream : h->chain_streams[c]; }
+
+// Start the chains off the handle's stream: everything queued on it so far is ahead of what the chains will run.
+int fork_chains(mt_handle h, int chains) {
+  if (h->forked) return MT_OK;
   int rc = ensure_chains(h, chains);
   if (rc) return rc;
   const int64_t span = chain_span(h, chains);
-  MT_HIP(h, hipEventRecord(h->ev_fork, root));
+  MT_HIP(h, hipEventRecord(h->ev_fork, h->stream));
   for (int c = 1; c < chains; ++c)
     if ((int64_t)c * span < h->n) MT_HIP(h, hipStreamWaitEvent(h->chain_streams[c], h->ev_fork, 0));
-  hipStream_t keep = h->stream;
-  for (int c = 0; c < chains && rc == MT_OK; ++c) {
-    if ((int64_t)c * span >= h->n) continue;
-    h->stream = c == 0 ? root : h->chain_streams[c];
-    rc = body(c);
-  }
-  h->stream = keep;
-  for (int c = 1; c < chains; ++c) {  // join even after a failure: nothing is left dangling off the root stream
-    if ((int64_t)c * span >= h->n) continue;
-    MT_HIP(h, hipEventRecord(h->ev_join[c], h->chain_streams[c]));
-    MT_HIP(h, hipStreamWaitEvent(root, h->ev_join[c], 0));
-  }
-  return rc;
+  h->forked = true;
+  return MT_OK;
 }
+
+// After a per-chain call: on the handle's private stream the chains may stay forked (the next per-chain call continues
+// them, any other call joins: MT_ENTER); on a caller's stream the call has to be complete in stream order when it returns.
+int settle_chains(mt_handle h) { return (h->lazy_chains && h->stream == h->own_stream) ? MT_OK : join_chains(h); }
 
 // The view of ONE env of the batch: every row base moved `env` elements to the right, n = 1.  The wavefront ballot
 // of such a launch goes to a spare word; the real done_bits word is rebuilt afterwards (done_bits_word_kernel).
@@ -445,6 +451,12 @@ static int64_t first_unusable(const float* v, int64_t count, uint32_t limit) {
   }
   return -1;
 }
+// Resets write MT_F_LAST_RETURN: an exchange that is still reading that row in place has to finish first.
+static int order_behind_inplace_gather(mt_handle h, hipStream_t stream) {
+  if (h->gather_pending && h->gather_inplace) MT_HIP(h, hipStreamWaitEvent(stream, h->ev_g1, 0));
+  return MT_OK;
+}
+
 constexpr uint32_t kMaxAngleBits = 0x47000000u;   // 32768.0f: the bound of unusable_angle (kernels.h)
 constexpr uint32_t kMaxFiniteBits = 0x7F7FFFFFu;  // FLT_MAX
 
@@ -562,6 +574,7 @@ int mt_create(mt_handle* out, const mt_config* cfg) {
   h->chains = (cfg->n_envs >= 163840 && cfg->n_envs <= 3145728) ? 2 : 1;
   if (const char* env = std::getenv("MT_CHAINS")) h->chains = std::max(1, std::min((int)mt_engine::kMaxChains, std::atoi(env)));
   if (cfg->n_envs < 2 * 256) h->chains = 1;
+  if (const char* env = std::getenv("MT_LAZY_CHAINS")) h->lazy_chains = std::atoi(env) != 0;  // 0: join at the end of every call
   h->prefetch_forced = false;
   if (const char* env = std::getenv("MT_PREFETCH")) {
     h->prefetch = std::atoi(env) != 0;
@@ -706,7 +719,7 @@ int mt_destroy(mt_handle h) {
   if (h->arena) (void)hipFree(h->arena);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
-  for (hipEvent_t e : h->lap_events) (void)hipEventDestroy(e);
+  for (hipEvent_t e : h->lap_events) (void)hipEventDestroy(e);  // (the whole pool)
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
   delete h;
   return MT_OK;
@@ -731,7 +744,7 @@ const char* mt_step_kernel_name(mt_handle h) {
 
 int mt_set_stream(mt_handle h, void* hip_stream) {
   MT_REQUIRE(nullptr, h != nullptr, "handle is NULL");
-  MT_ON_DEVICE(h, h->cfg.device);
+  MT_ENTER(h);
   MT_HIP(h, hipStreamSynchronize(h->stream));   // everything queued so far is finished before the ordering changes
   h->stream = (hipStream_t)hip_stream;          // NULL is a stream too: the legacy default stream
   return MT_OK;
@@ -739,7 +752,7 @@ int mt_set_stream(mt_handle h, void* hip_stream) {
 
 int mt_use_own_stream(mt_handle h) {
   MT_REQUIRE(nullptr, h != nullptr, "handle is NULL");
-  MT_ON_DEVICE(h, h->cfg.device);
+  MT_ENTER(h);
   MT_HIP(h, hipStreamSynchronize(h->stream));
   h->stream = h->own_stream;
   return MT_OK;
@@ -747,7 +760,7 @@ int mt_use_own_stream(mt_handle h) {
 
 int mt_sync(mt_handle h) {
   MT_REQUIRE(nullptr, h != nullptr, "handle is NULL");
-  MT_ON_DEVICE(h, h->cfg.device);  // the NULL stream names the CURRENT device's default stream
+  MT_ENTER(h);  // (also: the NULL stream names the CURRENT device's default stream)
   MT_HIP(h, hipStreamSynchronize(h->stream));
   if (h->gather_pending) {  // a gather begun on the side stream is part of "everything queued on this handle"
     MT_HIP(h, hipStreamSynchronize(h->side_stream));
@@ -766,7 +779,7 @@ int mt_reset(mt_handle h, const float* points, int layout, int is_device) {
     const int64_t bad = first_unusable(points, h->n * 3 * h->K, kMaxFiniteBits);
     if (bad >= 0) return fail(h, MT_ERR_INVALID_ARG, "mt_reset: points element " + std::to_string(bad) + " is NaN or infinite");
   }
-  MT_ON_DEVICE(h, h->cfg.device);
+  MT_ENTER(h);
   const int rows = 3 * h->K;
   if (layout == MT_SOA) {
     const size_t bytes = (size_t)rows * h->ld * 4;
@@ -786,6 +799,10 @@ int mt_reset(mt_handle h, const float* points, int layout, int is_device) {
     int rc = check_launch(h, "env_major_to_soa");
     if (rc) return rc;
   }
+  {
+    int rcg = order_behind_inplace_gather(h, h->stream);
+    if (rcg) return rcg;
+  }
   h->args.major = 0;  // caller-supplied targets start episode 0 of every env
   h->args.episode0 = 0;
   if (!h->goals_exposed) h->args.flags |= kFlagWholeGoals;  // every env is at the zero pose after this launch
@@ -800,6 +817,13 @@ int mt_reset(mt_handle h, const float* points, int layout, int is_device) {
 static int reset_random_impl(mt_handle h, uint64_t seed, uint32_t episode, int mode) {
   MT_REQUIRE(nullptr, h != nullptr, "handle is NULL");
   MT_ON_DEVICE(h, h->cfg.device);
+  // A full random reset of a multi-chain handle is issued per chain, behind that chain's own last step, and leaves the
+  // chains forked: one range's reset runs beside the other range's last step instead of behind a join.
+  const bool per_chain = mode == 1 && h->chains > 1 && h->lazy_chains;
+  if (!per_chain) {
+    int rc = join_chains(h);
+    if (rc) return rc;
+  }
   h->args.seed_lo = (uint32_t)seed;
   h->args.seed_hi = (uint32_t)(seed >> 32);
   h->args.major = episode;
@@ -807,8 +831,29 @@ static int reset_random_impl(mt_handle h, uint64_t seed, uint32_t episode, int m
     h->args.episode0 = episode;  // full reset: finished-episode counts restart from here
     if (!h->goals_exposed) h->args.flags |= kFlagWholeGoals;  // every env is at the zero pose after this launch
   }
+  if (per_chain) {
+    int rc = fork_chains(h, h->chains);
+    if (rc) return rc;
+    const int64_t span = chain_span(h, h->chains);
+    hipStream_t root = h->stream;
+    for (int c = 0; c < h->chains && rc == MT_OK; ++c) {
+      const int64_t off = (int64_t)c * span;
+      if (off >= h->n) continue;
+      const StepArgs ar = args_for_range(h, h->args, off, std::min(span, h->n - off));
+      h->stream = c == 0 ? root : h->chain_streams[c];
+      rc = order_behind_inplace_gather(h, h->stream);
+      if (rc == MT_OK) MT_DISPATCH_D(h->D, launch_reset_d, h, ar, 1);
+    }
+    h->stream = root;
+    if (rc == MT_OK) rc = check_launch(h, "reset_kernel (per chain)");
+    if (rc) return rc;
+    h->is_reset = true;
+    return settle_chains(h);
+  }
+  int rc = order_behind_inplace_gather(h, h->stream);
+  if (rc) return rc;
   MT_DISPATCH_D(h->D, launch_reset_d, h, h->args, mode);
-  int rc = check_launch(h, "reset_kernel");
+  rc = check_launch(h, "reset_kernel");
   if (rc) return rc;
   h->is_reset = true;
   return MT_OK;
@@ -828,7 +873,7 @@ int mt_set_actions(mt_handle h, const void* actions, int dtype, int layout, int 
   MT_REQUIRE(h, actions != nullptr, "actions is NULL");
   MT_REQUIRE(h, layout == MT_ENV_MAJOR || layout == MT_SOA, "bad layout");
   MT_REQUIRE(h, dtype == MT_F32 || dtype == MT_F64 || dtype == MT_I32 || dtype == MT_I64, "bad action dtype");
-  MT_ON_DEVICE(h, h->cfg.device);
+  MT_ENTER(h);
   const size_t es = (dtype == MT_F32 || dtype == MT_I32) ? 4 : 8;
   const int64_t cols = (layout == MT_SOA) ? h->ld : h->n;
   const size_t bytes = (size_t)h->D * cols * es;
@@ -868,7 +913,7 @@ int mt_set_actions(mt_handle h, const void* actions, int dtype, int layout, int 
 
 int mt_sample_actions(mt_handle h, uint64_t seed, uint32_t step_idx) {
   MT_REQUIRE(nullptr, h != nullptr, "handle is NULL");
-  MT_ON_DEVICE(h, h->cfg.device);
+  MT_ENTER(h);
   hipLaunchKernelGGL(sample_actions_kernel, grid_for(h->n), dim3(kBlock), 0, h->stream, h->args.actions, h->n, h->ld,
                      h->D, h->args.env_base, seed, step_idx);
   return check_launch(h, "sample_actions_kernel");
@@ -878,7 +923,7 @@ int mt_sample_actions(mt_handle h, uint64_t seed, uint32_t step_idx) {
 int mt_step(mt_handle h) {
   MT_REQUIRE(nullptr, h != nullptr, "handle is NULL");
   if (!h->is_reset) return fail(h, MT_ERR_STATE, "mt_step before mt_reset / mt_reset_random");
-  MT_ON_DEVICE(h, h->cfg.device);
+  MT_ENTER(h);
   launch_step(h, false);
   h->args.flags &= ~kFlagWholeGoals;  // staged actions are anybody's floats
   return check_launch(h, "step_kernel");
@@ -889,7 +934,7 @@ int mt_step_host(mt_handle h, const void* actions, int dtype, float* obs, int32_
   MT_REQUIRE(h, actions && obs && reward && done, "NULL argument");
   MT_REQUIRE(h, dtype == MT_F32 || dtype == MT_F64 || dtype == MT_I32 || dtype == MT_I64, "bad action dtype");
   if (!h->is_reset) return fail(h, MT_ERR_STATE, "mt_step_host before mt_reset / mt_reset_random");
-  MT_ON_DEVICE(h, h->cfg.device);
+  MT_ENTER(h);
   const size_t n = (size_t)h->n, es = (dtype == MT_F32 || dtype == MT_I32) ? 4 : 8;
   const size_t in_b = n * h->D * es, obs_b = n * 3 * h->K * 4, rew_b = n * 4, done_b = n;
   const size_t out_b = obs_b + rew_b + done_b, total = align_up(in_b, 256) + out_b;
@@ -939,7 +984,7 @@ int mt_step_host(mt_handle h, const void* actions, int dtype, float* obs, int32_
 int mt_step_random(mt_handle h, uint64_t seed, uint32_t step_idx) {
   MT_REQUIRE(nullptr, h != nullptr, "handle is NULL");
   if (!h->is_reset) return fail(h, MT_ERR_STATE, "mt_step_random before mt_reset / mt_reset_random");
-  MT_ON_DEVICE(h, h->cfg.device);
+  MT_ENTER(h);
   h->args.seed_lo = (uint32_t)seed;
   h->args.seed_hi = (uint32_t)(seed >> 32);
   h->args.major = step_idx;
@@ -959,7 +1004,7 @@ int mt_env_step(mt_handle h, int64_t env, const float* action, float* obs, int32
   MT_REQUIRE(h, action && obs && reward && done, "NULL argument");
   MT_REQUIRE(h, env >= 0 && env < h->n, "env index out of range");
   if (!h->is_reset) return fail(h, MT_ERR_STATE, "mt_env_step before mt_reset / mt_reset_random");
-  MT_ON_DEVICE(h, h->cfg.device);
+  MT_ENTER(h);
   const StepArgs a = args_for_env(h, env);
   const size_t pitch = (size_t)h->ld * 4;
   // column `env` of the D action rows <- D host floats
@@ -981,7 +1026,7 @@ int mt_env_reset(mt_handle h, int64_t env, const float* points, uint64_t seed, u
   MT_REQUIRE(nullptr, h != nullptr, "handle is NULL");
   MT_REQUIRE(h, env >= 0 && env < h->n, "env index out of range");
   if (!h->is_reset) return fail(h, MT_ERR_STATE, "mt_env_reset before the first reset of the batch");
-  MT_ON_DEVICE(h, h->cfg.device);
+  MT_ENTER(h);
   StepArgs a = args_for_env(h, env);
   if (points)  // (K, 3) host floats: flat index 3k + axis = row index
     MT_HIP(h, hipMemcpy2DAsync(a.points, (size_t)h->ld * 4, points, 4, 4, (size_t)(3 * h->K), hipMemcpyHostToDevice,
@@ -989,6 +1034,10 @@ int mt_env_reset(mt_handle h, int64_t env, const float* points, uint64_t seed, u
   a.seed_lo = (uint32_t)seed;
   a.seed_hi = (uint32_t)(seed >> 32);
   a.major = episode;
+  {
+    int rcg = order_behind_inplace_gather(h, h->stream);
+    if (rcg) return rcg;
+  }
   MT_DISPATCH_D(h->D, launch_reset_d, h, a, points ? 0 : 1);
   int rc = check_launch(h, "reset_kernel (one env)");
   if (rc) return rc;
@@ -1001,7 +1050,7 @@ int mt_env_reset(mt_handle h, int64_t env, const float* points, uint64_t seed, u
 int mt_bad_action_count(mt_handle h, uint64_t* count) {
   MT_REQUIRE(nullptr, h != nullptr, "handle is NULL");
   MT_REQUIRE(h, count != nullptr, "count is NULL");
-  MT_ON_DEVICE(h, h->cfg.device);
+  MT_ENTER(h);
   uint32_t c = 0;
   MT_HIP(h, hipMemcpyAsync(&c, h->args.bad_actions, 4, hipMemcpyDeviceToHost, h->stream));
   MT_HIP(h, hipStreamSynchronize(h->stream));
@@ -1093,7 +1142,7 @@ int mt_rollout(mt_handle h, int n_steps, uint64_t seed, uint32_t step_idx0) {
   MT_REQUIRE(h, n_steps >= 0, "n_steps must be >= 0");
   if (n_steps > 0 && !h->is_reset) return fail(h, MT_ERR_STATE, "mt_rollout before mt_reset / mt_reset_random");
   if (n_steps == 0) return MT_OK;
-  MT_ON_DEVICE(h, h->cfg.device);
+  MT_ON_DEVICE(h, h->cfg.device);  // per-chain call: joins only where it has to (below)
   // several independent chains of launches (env ranges on separate streams) where that pays; a caller who is capturing
   // the handle's stream gets the plain single-stream sequence
   int chains = (n_steps >= 2 && !h->trace) ? h->chains : 1;
@@ -1116,31 +1165,38 @@ int mt_rollout(mt_handle h, int n_steps, uint64_t seed, uint32_t step_idx0) {
       graph = false;
     }
   }
+  if (chains == 1) {  // single-stream forms: the chains (if a per-chain reset left them forked) come back first
+    int rc = join_chains(h);
+    if (rc) return rc;
+  }
   if (graph) {
     const mt_engine::RolloutGraph* rg = nullptr;
     int rc = rollout_graph(h, n_steps, seed, chains, &rg);
     if (rc) return rc;
-    MT_HIP(h, hipMemsetD32Async((hipDeviceptr_t)h->graph_step0, (int)step_idx0, 1, h->stream));
     if (chains > 1) {
-      rc = fork_join_chains(h, h->stream, chains, [&](int c) -> int {
-        MT_HIP(h, hipGraphLaunch(rg->exec[c], h->stream));
-        return MT_OK;
-      });
+      // the word every node adds to its step offset is set on the handle's stream BEFORE the fork (while forked, by
+      // joining first: a chain may still be replaying the previous segment, which reads the same word)
+      rc = join_chains(h);
+      if (rc) return rc;
+      MT_HIP(h, hipMemsetD32Async((hipDeviceptr_t)h->graph_step0, (int)step_idx0, 1, h->stream));
+      rc = fork_chains(h, chains);
+      if (rc) return rc;
+      const int64_t span = chain_span(h, chains);
+      for (int c = 0; c < chains; ++c)
+        if ((int64_t)c * span < h->n) MT_HIP(h, hipGraphLaunch(rg->exec[c], chain_stream(h, c)));
+      rc = settle_chains(h);
       if (rc) return rc;
     } else {
+      MT_HIP(h, hipMemsetD32Async((hipDeviceptr_t)h->graph_step0, (int)step_idx0, 1, h->stream));
       MT_HIP(h, hipGraphLaunch(rg->exec[0], h->stream));
     }
   } else if (chains > 1) {
     StepArgs a = h->args;
     a.seed_lo = (uint32_t)seed;
     a.seed_hi = (uint32_t)(seed >> 32);
-    // chains enqueued round-robin step by step, so that no stream runs dry while the host is busy with another one
-    int rc = ensure_chains(h, chains);
+    int rc = fork_chains(h, chains);  // no-op when a per-chain reset (or the previous segment) left them forked
     if (rc) return rc;
-    const int64_t span = chain_span(h, chains);
-    MT_HIP(h, hipEventRecord(h->ev_fork, h->stream));
-    for (int c = 1; c < chains; ++c)
-      if ((int64_t)c * span < h->n) MT_HIP(h, hipStreamWaitEvent(h->chain_streams[c], h->ev_fork, 0));
+    // chains enqueued round-robin step by step, so that no stream runs dry while the host is busy with another one
     hipStream_t root = h->stream;
     for (int st = 0; st < n_steps; ++st)
       for (int c = 0; c < chains; ++c) {
@@ -1149,11 +1205,8 @@ int mt_rollout(mt_handle h, int n_steps, uint64_t seed, uint32_t step_idx0) {
       }
     h->stream = root;
     rc = check_launch(h, "step_kernel (chained)");
-    for (int c = 1; c < chains; ++c) {
-      if ((int64_t)c * span >= h->n) continue;
-      MT_HIP(h, hipEventRecord(h->ev_join[c], h->chain_streams[c]));
-      MT_HIP(h, hipStreamWaitEvent(root, h->ev_join[c], 0));
-    }
+    if (rc) return rc;
+    rc = settle_chains(h);
     if (rc) return rc;
   } else {
     for (int s = 0; s < n_steps; ++s) {
@@ -1187,9 +1240,13 @@ int mt_rollout_fused(mt_handle h, int n_steps, uint64_t seed, uint32_t step_idx0
     }
     return MT_OK;
   }
-  MT_ON_DEVICE(h, h->cfg.device);
+  MT_ENTER(h);
   h->args.seed_lo = (uint32_t)seed;
   h->args.seed_hi = (uint32_t)(seed >> 32);
+  if (auto_reset) {  // the in-kernel re-arm writes MT_F_LAST_RETURN
+    int rcg = order_behind_inplace_gather(h, h->stream);
+    if (rcg) return rcg;
+  }
   RolloutArgs r{n_steps, step_idx0, auto_reset ? 1u : 0u, h->cfg.radius};
   if (h->static_kind == 1)
     launch_rollout_t<Ref4Table>(h, r);
@@ -1211,7 +1268,7 @@ int mt_rollout_fused(mt_handle h, int n_steps, uint64_t seed, uint32_t step_idx0
 int mt_observe(mt_handle h) {
   MT_REQUIRE(nullptr, h != nullptr, "handle is NULL");
   if (!h->is_reset) return fail(h, MT_ERR_STATE, "mt_observe before reset");
-  MT_ON_DEVICE(h, h->cfg.device);
+  MT_ENTER(h);
   MT_DISPATCH_D(h->D, launch_observe_d, h);
   return check_launch(h, "observe_kernel");
 }
@@ -1219,7 +1276,7 @@ int mt_observe(mt_handle h) {
 int mt_check_done(mt_handle h) {
   MT_REQUIRE(nullptr, h != nullptr, "handle is NULL");
   if (!h->is_reset) return fail(h, MT_ERR_STATE, "mt_check_done before reset");
-  MT_ON_DEVICE(h, h->cfg.device);
+  MT_ENTER(h);
   MT_DISPATCH_D(h->D, launch_check_done_d, h);
   return check_launch(h, "check_done_kernel");
 }
@@ -1254,7 +1311,7 @@ int mt_get(mt_handle h, int field, void* dst, int64_t dst_bytes, int is_device) 
   const int64_t need = env_major_bytes(h, field);
   MT_REQUIRE(h, need > 0, "unknown field (or a field this handle was created without)");
   MT_REQUIRE(h, dst_bytes == need, "dst_bytes does not match the field's env-major size");
-  MT_ON_DEVICE(h, h->cfg.device);
+  MT_ENTER(h);
   const dim3 g = grid_for(h->n), b(kBlock);
   void* out = dst;
   if (!is_device) {
@@ -1312,7 +1369,7 @@ int mt_set(mt_handle h, int field, const void* src, int64_t src_bytes) {
       return fail(h, MT_ERR_INVALID_ARG, "mt_set: element " + std::to_string(bad) + " is NaN, infinite or (joint angles) beyond "
                                          "+-32768 degrees");
   }
-  MT_ON_DEVICE(h, h->cfg.device);
+  MT_ENTER(h);
   const dim3 g = grid_for(h->n), b(kBlock);
   const StepArgs& a = h->args;
   void* row = field == MT_F_TOTAL_REWARD ? (void*)a.total_reward : field == MT_F_DONE ? (void*)a.done :
@@ -1372,6 +1429,7 @@ int mt_device_ptr(mt_handle h, int field, void** ptr, int64_t* rows, int64_t* ld
 // ---- timing -----------------------------------------------------------------------------------
 int mt_timer_start(mt_handle h) {
   MT_REQUIRE(nullptr, h != nullptr, "handle is NULL");
+  MT_ENTER(h);
   MT_HIP(h, hipEventRecord(h->ev0, h->stream));
   return MT_OK;
 }
@@ -1379,49 +1437,84 @@ int mt_timer_start(mt_handle h) {
 int mt_timer_stop(mt_handle h, float* elapsed_ms) {
   MT_REQUIRE(nullptr, h != nullptr, "handle is NULL");
   MT_REQUIRE(h, elapsed_ms != nullptr, "elapsed_ms is NULL");
+  MT_ENTER(h);
   MT_HIP(h, hipEventRecord(h->ev1, h->stream));
   MT_HIP(h, hipEventSynchronize(h->ev1));
   MT_HIP(h, hipEventElapsedTime(elapsed_ms, h->ev0, h->ev1));
   return MT_OK;
 }
 
-static int lap_record(mt_handle h) {
-  if (h->laps_used == h->lap_events.size()) {
+// one event of the lap pool, recorded on `stream`; its index
+static int lap_event(mt_handle h, hipStream_t stream, uint32_t* index) {
+  if (h->lap_events_used == h->lap_events.size()) {
     hipEvent_t e = nullptr;
-    DeviceGuard guard(h->cfg.device);
     MT_HIP(h, hipEventCreate(&e));
     h->lap_events.push_back(e);
   }
-  MT_HIP(h, hipEventRecord(h->lap_events[h->laps_used], h->stream));
-  ++h->laps_used;
+  MT_HIP(h, hipEventRecord(h->lap_events[h->lap_events_used], stream));
+  *index = (uint32_t)h->lap_events_used++;
   return MT_OK;
 }
 
 int mt_timer_lap_begin(mt_handle h) {
   MT_REQUIRE(nullptr, h != nullptr, "handle is NULL");
   if (h->lap_open) return fail(h, MT_ERR_STATE, "mt_timer_lap_begin: a lap is already open");
-  int rc = lap_record(h);
-  if (rc == MT_OK) h->lap_open = true;
-  return rc;
+  MT_ENTER(h);  // a lap starts on the handle's stream with everything before it folded in
+  mt_engine::LapRec rec{0, 0, 0};
+  int rc = lap_event(h, h->stream, &rec.begin);
+  if (rc) return rc;
+  h->lap_recs.push_back(rec);
+  h->lap_open = true;
+  return MT_OK;
 }
 
 int mt_timer_lap_end(mt_handle h) {
   MT_REQUIRE(nullptr, h != nullptr, "handle is NULL");
   if (!h->lap_open) return fail(h, MT_ERR_STATE, "mt_timer_lap_end without mt_timer_lap_begin");
+  MT_ON_DEVICE(h, h->cfg.device);  // NOT a join: while the chains are forked the lap ends when the last of them is done
+  mt_engine::LapRec& rec = h->lap_recs.back();
+  int rc = lap_event(h, h->stream, &rec.end0);
+  if (rc) return rc;
+  rec.n_end = 1;
+  if (h->forked)
+    for (int c = 1; c < h->chains; ++c) {
+      if (!h->chain_streams[c] || (int64_t)c * chain_span(h, h->chains) >= h->n) continue;
+      uint32_t idx;
+      rc = lap_event(h, h->chain_streams[c], &idx);  // consecutive indices: end0, end0 + 1, ...
+      if (rc) return rc;
+      ++rec.n_end;
+    }
   h->lap_open = false;
-  return lap_record(h);
+  return MT_OK;
+}
+
+// milliseconds of lap `rec`: from its begin to the latest of its end events
+static int lap_ms(mt_handle h, const mt_engine::LapRec& rec, float* ms) {
+  float best = 0.f;
+  for (uint32_t k = 0; k < rec.n_end; ++k) {
+    float v = 0.f;
+    MT_HIP(h, hipEventSynchronize(h->lap_events[rec.end0 + k]));
+    MT_HIP(h, hipEventElapsedTime(&v, h->lap_events[rec.begin], h->lap_events[rec.end0 + k]));
+    best = v > best ? v : best;
+  }
+  *ms = best;
+  return MT_OK;
 }
 
 int mt_timer_lap_times(mt_handle h, float* ms, int capacity, int* n_laps) {
   MT_REQUIRE(nullptr, h != nullptr, "handle is NULL");
   MT_REQUIRE(h, n_laps != nullptr && (ms != nullptr || capacity == 0), "NULL argument");
   if (h->lap_open) return fail(h, MT_ERR_STATE, "mt_timer_lap_times: a lap is still open");
-  const size_t laps = h->laps_used / 2;
+  const size_t laps = h->lap_recs.size();
   *n_laps = (int)laps;
   if ((size_t)capacity < laps) return fail(h, MT_ERR_INVALID_ARG, "mt_timer_lap_times: capacity is smaller than the number of laps");
-  if (laps) MT_HIP(h, hipEventSynchronize(h->lap_events[h->laps_used - 1]));
-  for (size_t i = 0; i < laps; ++i) MT_HIP(h, hipEventElapsedTime(&ms[i], h->lap_events[2 * i], h->lap_events[2 * i + 1]));
-  h->laps_used = 0;
+  MT_ON_DEVICE(h, h->cfg.device);
+  for (size_t i = 0; i < laps; ++i) {
+    int rc = lap_ms(h, h->lap_recs[i], &ms[i]);
+    if (rc) return rc;
+  }
+  h->lap_recs.clear();
+  h->lap_events_used = 0;
   return MT_OK;
 }
 
@@ -1429,17 +1522,18 @@ int mt_timer_laps_total(mt_handle h, float* total_ms, int* n_laps) {
   MT_REQUIRE(nullptr, h != nullptr, "handle is NULL");
   MT_REQUIRE(h, total_ms != nullptr, "total_ms is NULL");
   if (h->lap_open) return fail(h, MT_ERR_STATE, "mt_timer_laps_total: a lap is still open");
+  MT_ON_DEVICE(h, h->cfg.device);
   double sum = 0.0;
-  const size_t laps = h->laps_used / 2;
-  if (laps) MT_HIP(h, hipEventSynchronize(h->lap_events[h->laps_used - 1]));
-  for (size_t i = 0; i < laps; ++i) {
-    float ms = 0.f;
-    MT_HIP(h, hipEventElapsedTime(&ms, h->lap_events[2 * i], h->lap_events[2 * i + 1]));
-    sum += ms;
+  for (const auto& rec : h->lap_recs) {
+    float v = 0.f;
+    int rc = lap_ms(h, rec, &v);
+    if (rc) return rc;
+    sum += v;
   }
   *total_ms = (float)sum;
-  if (n_laps) *n_laps = (int)laps;
-  h->laps_used = 0;
+  if (n_laps) *n_laps = (int)h->lap_recs.size();
+  h->lap_recs.clear();
+  h->lap_events_used = 0;
   return MT_OK;
 }
 

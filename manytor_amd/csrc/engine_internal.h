@@ -18,8 +18,14 @@ struct mt_engine {
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  std::vector<hipEvent_t> lap_events;  // begin/end pairs recorded by mt_timer_lap_*; grown on demand
-  size_t laps_used = 0;                // events in use (2 per lap)
+  // mt_timer_lap_*: a lap = one begin event on the handle's stream + one end event per stream that carried work of the lap
+  // (the handle's stream, and the chain streams while mt_rollout's chains are forked); its time = begin -> the latest end
+  struct LapRec {
+    uint32_t begin, end0, n_end;  // indices into lap_events
+  };
+  std::vector<hipEvent_t> lap_events;  // event pool, grown on demand
+  size_t lap_events_used = 0;
+  std::vector<LapRec> lap_recs;
   bool lap_open = false;
   void* arena = nullptr;
   size_t arena_bytes = 0;
@@ -70,7 +76,13 @@ struct mt_engine {
   bool chain_prefetch = false;
   hipStream_t chain_streams[kMaxChains] = {nullptr, nullptr, nullptr, nullptr};  // [0] unused: chain 0 runs on `stream`
   hipEvent_t ev_fork = nullptr, ev_join[kMaxChains] = {nullptr, nullptr, nullptr, nullptr};
+  // Chains stay forked ACROSS calls while the handle runs on its own stream: mt_rollout and mt_reset_random enqueue per
+  // chain and return; every other entry point joins first (MT_ENTER), mt_sync included, so "sync before foreign reads"
+  // keeps its meaning.  On a caller's stream (mt_set_stream) every call joins before it returns, as stream order demands.
+  bool forked = false;
+  bool lazy_chains = true;  // MT_LAZY_CHAINS=0: every per-chain call joins before it returns, resets are never per chain
   bool gather_pending = false;
+  bool gather_inplace = false;  // the pending exchange reads an arena row directly (mt_gather_returns_begin_inplace): resets wait for it
   float last_gather_ms = 0.f;  // device time of the last exchange that was waited for (mt_gather_returns_wait / mt_sync)
   std::string err;
   std::string kernel_name;  // mt_step_kernel_name
@@ -103,6 +115,9 @@ class DeviceGuard {
 
 inline dim3 grid_for(int64_t n) { return dim3((unsigned)((n + kBlock - 1) / kBlock)); }
 
+// engine.hip: the handle's stream waits for everything the chain streams still carry (no-op when not forked)
+int join_chains(mt_handle h);
+
 }  // namespace mt
 
 #define MT_HIP(h, call)                                                                            \
@@ -121,6 +136,17 @@ inline dim3 grid_for(int64_t n) { return dim3((unsigned)((n + kBlock - 1) / kBlo
   mt::DeviceGuard mt_guard__(device);                                                                    \
   if (mt_guard__.error() != hipSuccess)                                                                  \
   return mt::fail(h, MT_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(mt_guard__.error()))
+
+// Entry of every call that touches the handle's device state as a whole: make the handle's device current and fold the
+// chains back into the handle's stream.  (mt_rollout and mt_reset_random, which work per chain, use MT_ON_DEVICE.)
+#define MT_ENTER(h)                      \
+  MT_ON_DEVICE(h, (h)->cfg.device);      \
+  do {                                   \
+    if ((h)->forked) {                   \
+      int rcj__ = mt::join_chains(h);    \
+      if (rcj__ != MT_OK) return rcj__;  \
+    }                                    \
+  } while (0)
 
 // comm.hip
 void mt_comm_release(mt_handle h);

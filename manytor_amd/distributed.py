@@ -235,7 +235,7 @@ def attach_torch_gather(engine, n_total: int, rank: int, world_size: int, group=
         return out
 
     engine.gather_returns = gather_returns
-    engine.gather_begin = gather_returns
+    engine.gather_begin = lambda out=None, field=None, row=0, snapshot=True: gather_returns(out, field, row)
     engine.gather_wait = lambda host=False: 0.0 if host else None
     engine.total_envs = lambda: n_total
     return engine
@@ -270,7 +270,9 @@ def attach_gloo_gather(engine, n_total: int, rank: int, world_size: int, group=N
     import torch
 
     def gather_returns(out=None, field=None, row=0):
-        local = torch.from_numpy(engine.total_reward())
+        from . import _lib as L
+        vals = engine.get(L.F_TOTAL_REWARD if field is None else field)
+        local = torch.from_numpy(vals if vals.ndim == 1 else np.ascontiguousarray(vals[:, row]))
         full = gloo_gather_returns(local, n_total, group)
         if out is None:
             out = torch.empty(n_total, dtype=torch.float32, device=f"cuda:{engine.device}")
@@ -278,7 +280,7 @@ def attach_gloo_gather(engine, n_total: int, rank: int, world_size: int, group=N
         return out
 
     engine.gather_returns = gather_returns
-    engine.gather_begin = gather_returns          # the stand-in does not overlap anything
+    engine.gather_begin = lambda out=None, field=None, row=0, snapshot=True: gather_returns(out, field, row)   # no overlap
     engine.gather_wait = lambda host=False: 0.0 if host else None
     engine.total_envs = lambda: n_total
     return engine

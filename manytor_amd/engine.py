@@ -519,13 +519,16 @@ class StepEngine:
             raise ValueError(f"out must be a contiguous float32 device tensor of {n_total} elements")
         return out, n_total
 
-    def gather_begin(self, out=None, field=None, row=0):
-        """Start the all-gather of one return row on the engine's side stream (from a snapshot taken on its main stream)
-        and return at once: steps and resets queued next overlap with the exchange.  `out` is complete after
-        gather_wait(host=True) or sync()."""
+    def gather_begin(self, out=None, field=None, row=0, snapshot=True):
+        """Start the all-gather of one return row on the engine's side stream and return at once: steps and resets queued
+        next overlap with the exchange.  `out` is complete after gather_wait(host=True) or sync().  By default the row is
+        snapshotted on the main stream first (so a reset queued next may overwrite it); `snapshot=False` lets the exchange
+        read the row in place -- for MT_F_LAST_RETURN right after the reset that ended the episode (that row is written by
+        resets only, and the library orders its later resets behind the exchange)."""
         field = L.F_TOTAL_REWARD if field is None else field
         out, n_total = self._gather_out(out)
-        self._call(self._lib.mt_gather_returns_begin, int(field), int(row), C.c_void_p(out.data_ptr()), C.c_int64(n_total))
+        fn = self._lib.mt_gather_returns_begin if snapshot else self._lib.mt_gather_returns_begin_inplace
+        self._call(fn, int(field), int(row), C.c_void_p(out.data_ptr()), C.c_int64(n_total))
         return out
 
     def gather_wait(self, host=False):

@@ -25,7 +25,7 @@ from oracle import philox_ref as px  # noqa: E402
 
 FIELDS = ("F_GOALS", "F_ALIVE", "F_TOTAL_REWARD", "F_POINTS", "F_EPISODES", "F_LAST_RETURN", "F_OBS", "F_REWARD", "F_DONE",
           "F_EE", "F_DONE_BITS", "F_ZMIN", "F_RETURN_RING")
-KNOBS = ("MT_CHAINS", "MT_GRAPH", "MT_TRIG_TABLE", "MT_SPLIT", "MT_PREFETCH", "MT_RESET_SPLIT")
+KNOBS = ("MT_CHAINS", "MT_GRAPH", "MT_TRIG_TABLE", "MT_SPLIT", "MT_PREFETCH", "MT_RESET_SPLIT", "MT_LAZY_CHAINS")
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--minutes", type=float, default=3.0)
@@ -57,9 +57,11 @@ while time.time() < deadline:
         k = 7
     tol = float(rng.choice([3.0, 8.0, 25.0]))
     seed = int(rng.randint(1, 1 << 30))
-    plan = [(str(rng.choice(["rollout", "rollout", "fused", "fused_auto"])), int(rng.randint(1, 12))) for _ in range(int(rng.randint(2, 5)))]
+    plan = [(str(rng.choice(["rollout", "rollout", "fused", "fused_auto", "rollout_reset", "rollout_gather_reset"])), int(rng.randint(1, 12)))
+            for _ in range(int(rng.randint(2, 6)))]
     knobs = {"MT_CHAINS": rng.randint(1, 5), "MT_GRAPH": rng.randint(2), "MT_TRIG_TABLE": rng.randint(2),
-             "MT_SPLIT": rng.choice([0, 2, 4]), "MT_PREFETCH": rng.randint(2), "MT_RESET_SPLIT": rng.randint(2)}
+             "MT_SPLIT": rng.choice([0, 2, 4]), "MT_PREFETCH": rng.randint(2), "MT_RESET_SPLIT": rng.randint(2),
+             "MT_LAZY_CHAINS": int(rng.rand() < 0.8)}
 
     def run(env):
         for key in KNOBS:
@@ -68,25 +70,42 @@ while time.time() < deadline:
         e.reset_random(seed, 3)
         p0 = e.points()
         t = 0
+        episode = 3
+        gathered = []
         for what, steps in plan:
             for _ in range(2):                       # twice: the second request of a segment length may replay a graph
                 if what == "rollout":
                     e.rollout(steps, seed, t)
                     e.reset_done(seed)
+                elif what == "rollout_reset":        # a full reset right behind a segment: per chain while the chains are forked
+                    e.rollout(steps, seed, t)
+                    episode += 1
+                    e.reset_random(seed, episode)
+                elif what == "rollout_gather_reset":  # the benchmark's episode end: snapshot gather (per chain), then the reset
+                    e.rollout(steps, seed, t)
+                    gathered.append(e.gather_begin())
+                    episode += 1
+                    e.reset_random(seed, episode)
                 else:
                     e.rollout_fused(steps, seed, t, auto_reset=(what == "fused_auto"))
                 t += steps
+        if gathered:
+            e.gather_wait(host=True)
         e.rollout(2, seed, t)                        # the last step: per-step launches in both runs
         out = {f: e.get(getattr(m.lib, f)) for f in FIELDS}
+        for i, g_ in enumerate(gathered):
+            out[f"gathered{i}"] = g_.cpu().numpy()
         e.close()
         return out, p0, t + 2
 
-    plain, p0, total = run({"MT_CHAINS": 1, "MT_GRAPH": 0, "MT_TRIG_TABLE": 0, "MT_SPLIT": 0, "MT_PREFETCH": 0, "MT_RESET_SPLIT": 0})
+    plain, p0, total = run({"MT_CHAINS": 1, "MT_GRAPH": 0, "MT_TRIG_TABLE": 0, "MT_SPLIT": 0, "MT_PREFETCH": 0, "MT_RESET_SPLIT": 0,
+                            "MT_LAZY_CHAINS": 0})
     got, p1, _ = run(knobs)
-    for f in FIELDS:
+    for f in plain:
         assert np.array_equal(plain[f], got[f]), (f, knobs, n, k, dof, substeps, plan, seed)
     ids = np.arange(n, dtype=np.uint64)
     assert np.array_equal(p0, px.sample_targets(seed, ids, 3, k, radius)) and np.array_equal(p0, p1), (knobs, n, k)
+    # (F_POINTS of the final state are the targets of the last full reset / re-arm: compared bit for bit above)
     # the last step against the oracle: it only needs the pose before it (= the action of the step before) and the action
     # (the z-minimum and the end effector of the last step depend only on the two last actions: the pose before the last
     # step is the action of the step before it, whatever happened to the env earlier)

@@ -180,6 +180,7 @@ class _FakeEngine:
         self.laps = []
 
     def reset_random(self, seed, episode):
+        self.last = self.ret.clone()                      # the reset stores the finished return, then zeroes
         self.ret.zero_()
         self.resets += 1
 
@@ -189,10 +190,11 @@ class _FakeEngine:
 
     rollout_fused = rollout
 
-    def gather_returns(self, out=None):
+    def gather_returns(self, out=None, field=None, snapshot=True):
         self.gathers += 1
         ids = torch.arange(self.base, self.base + self.n, dtype=torch.float32) if self.tag_ids else 0.0
-        return D.gloo_gather_returns(self.ret + ids / 1e6, self.n_total)
+        src = self.last if field is not None else self.ret       # MT_F_LAST_RETURN (what the reset kept) or the live returns
+        return D.gloo_gather_returns(src + ids / 1e6, self.n_total)
 
     gather_begin = gather_returns
 

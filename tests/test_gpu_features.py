@@ -421,3 +421,98 @@ def test_writing_goals_through_the_raw_pointer_is_seen_by_the_sampled_step(m):
     ora.step(e.goals().astype(np.float64))
     assert np.abs(e.zmin() - ora.zmin).max() <= 1e-4          # the route really started at the fractional pose
     assert np.abs(e.ee() - ora.joints_coordinates[:, -1]).max() <= 1e-4
+
+
+@pytest.mark.parametrize("chains", [2, 3])
+def test_chains_stay_forked_across_reset_and_rollout_and_join_where_they_must(m, monkeypatch, chains):
+    """On its own stream a multi-chain handle does not join after mt_rollout / mt_reset_random: each env range is reset
+    right behind its own last step and the next segment continues per chain.  Every other call folds the chains back
+    first (MT_ENTER): the in-place gather of MT_F_LAST_RETURN begun after a reset must deliver the finished returns of
+    EVERY range while the next episode is already running, getters and reset_done must see complete state, and the
+    whole sequence must equal the single-chain engine bit for bit."""
+    import torch
+    n, k = 300003, 3
+    monkeypatch.setenv("MT_CHAINS", "1")
+    ref = m.StepEngine(n, k, pickup_tol=20.0)
+    monkeypatch.setenv("MT_CHAINS", str(chains))
+    eng = m.StepEngine(n, k, pickup_tol=20.0)
+    assert f"{chains} chains" in eng.step_kernel_name()
+    returns = {}
+    for e in (ref, eng):
+        e.reset_random(8, 0)
+        e.rollout(7, 8, 0)                                   # forked from here on (eng)
+        e.reset_random(8, 1)                                 # per chain, no join
+        buf = e.gather_begin(field=m.lib.F_LAST_RETURN, snapshot=False)      # joins; exchange on the side stream
+        e.rollout(5, 8, 0)                                   # next episode beside the exchange
+        e.reset_random(8, 2)                                 # must wait for the exchange: it overwrites MT_F_LAST_RETURN
+        e.rollout(4, 8, 0)
+        e.gather_wait(host=True)
+        returns[e] = buf.cpu().numpy().copy()
+        e.reset_done(8)                                      # a whole-batch call right behind per-chain work
+        e.rollout(3, 8, 4)
+    np.testing.assert_array_equal(returns[eng], returns[ref])
+    assert np.abs(returns[ref]).max() > 0                    # the 7-step episode's returns, not the zeros after the reset
+    for f in ("F_GOALS", "F_ALIVE", "F_TOTAL_REWARD", "F_POINTS", "F_EPISODES", "F_LAST_RETURN", "F_OBS", "F_REWARD", "F_DONE",
+              "F_EE", "F_DONE_BITS"):
+        np.testing.assert_array_equal(eng.get(getattr(m.lib, f)), ref.get(getattr(m.lib, f)), err_msg=f)
+    # sync() is a join point too: a torch read of a view after it sees every range
+    eng.rollout(6, 8, 7)
+    ref.rollout(6, 8, 7)
+    eng.sync()
+    view = eng.device_tensor(m.lib.F_TOTAL_REWARD).clone()
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(view.cpu().numpy(), ref.total_reward())
+
+
+def test_lap_timer_covers_every_chain(m, monkeypatch):
+    """A lap that ends while the chains are forked ends when the LAST chain is done (one end event per stream), so a
+    2-chain lap over T steps reads like the same work timed with a full join -- not like half of it."""
+    n, k, T = 1048576, 7, 20
+    monkeypatch.setenv("MT_CHAINS", "2")
+    e = m.StepEngine(n, k)
+    e.reset_random(1, 0)
+    for _ in range(5):
+        e.rollout(50, 1, 0)
+    e.sync()
+    e.lap_times()
+    laps, joined = [], []
+    for r in range(8):
+        e.reset_random(1, r)
+        e.sync()
+        e.lap_begin()
+        e.rollout(T, 1, 0)                                   # leaves the chains forked
+        e.lap_end()
+        laps.extend(e.lap_times())
+        e.sync()
+        e.timer_start()                                      # timer_start / timer_stop join
+        e.rollout(T, 1, T)
+        joined.append(e.timer_stop())
+    lap, ref = np.median(laps), np.median(joined)
+    assert 0.85 * ref <= lap <= 1.1 * ref, (lap, ref)
+    assert lap * 1e3 / T > 25.0                              # us per step of 1 M arms: not half a step
+
+
+def test_snapshot_gather_taken_per_chain_while_forked(m, monkeypatch):
+    """mt_gather_returns_begin on a handle whose chains are forked snapshots every env range on its own chain (no join) and
+    the chains stay forked for the per-chain reset queued next: the gathered returns must still be those of the finished
+    episode for EVERY range, equal to what a single-chain engine gathers."""
+    n, k = 400003, 2
+    out = {}
+    for chains in ("1", "2", "3"):
+        monkeypatch.setenv("MT_CHAINS", chains)
+        e = m.StepEngine(n, k)
+        e.reset_random(3, 0)
+        e.rollout(9, 3, 0)                                   # forked
+        a = e.gather_begin()                                 # per-chain snapshot
+        e.reset_random(3, 1)                                 # per chain, beside the exchange: must not leak zeros into `a`
+        e.rollout(6, 3, 0)
+        e.gather_wait()                                      # orders the handle's stream behind the first exchange
+        b = e.gather_begin()                                 # second exchange: the snapshot buffer is reused behind the first
+        e.reset_random(3, 2)
+        e.gather_wait(host=True)
+        e.sync()
+        out[chains] = (a.cpu().numpy().copy(), b.cpu().numpy().copy(), e.total_reward())
+    for chains in ("2", "3"):
+        for x, y in zip(out[chains], out["1"]):
+            np.testing.assert_array_equal(x, y)
+    assert np.abs(out["1"][0]).max() > 0 and np.abs(out["1"][1]).max() > 0 and not out["1"][2].any()
