@@ -709,7 +709,7 @@ def main():
                         "the chains included.  With launches_per_step = 2 a step is two CONCURRENT launches of "
                         "envs_per_launch envs on two streams: rocprofv3's per-launch average (34.7 us for 524 288 envs, "
                         "profiles/r03_kernel_stats_by_grid.csv) is then the duration of each of two overlapping kernels, "
-                        "not half a step; the union of their intervals per step (35.2 us, same file, last line) is the "
+                        "not half a step; the union of their intervals per step (35.7 us, same file, last line) is the "
                         "figure that corresponds to avg_kernel_us",
             },
         }
