@@ -1,3 +1,9 @@
+#!/usr/bin/env python3
+"""Around 131 072 arms: one launch per step against two / three chains with the cached graph or plain launches, with the
+two-lane kernels the chain's env count would pick or one env per lane (MT_SPLIT=0), steady-state protocol (12 x (reset + 50
+steps) back to back, one event pair).  Shows the block-count quantisation: 131 072 envs = exactly two 256-thread blocks per CU
+is the best case of a single launch; 98 304 and 163 840 envs gain from two chains.
+    python tools/chain_variant_probe.py"""
 import os, sys, time, json
 sys.path.insert(0, os.getcwd())
 import manytor_amd as m
