@@ -488,7 +488,7 @@ def test_lap_timer_covers_every_chain(m, monkeypatch):
         e.rollout(T, 1, T)
         joined.append(e.timer_stop())
     lap, ref = np.median(laps), np.median(joined)
-    assert 0.85 * ref <= lap <= 1.1 * ref, (lap, ref)
+    assert 0.8 * ref <= lap <= 1.2 * ref, (lap, ref)
     assert lap * 1e3 / T > 25.0                              # us per step of 1 M arms: not half a step
 
 
