@@ -1148,3 +1148,49 @@ def test_rollout_in_independent_chains_equals_plain_launches(m, monkeypatch, n, 
     ref.rollout(9, 6, 18)
     for f in fields:
         np.testing.assert_array_equal(e.get(getattr(m.lib, f)), ref.get(getattr(m.lib, f)), err_msg=f)
+
+
+@pytest.mark.parametrize("table_name", ["ref", "dh7"])
+@pytest.mark.parametrize("n,expect", [(32768, "L=4"), (65536, "L=2"), (131072, "pf=8"), (1048576, None)])
+def test_staged_action_step_every_env_against_the_c_oracle(m, table_name, n, expect):
+    """The policy-in-the-loop path -- mt_set_actions + mt_step, i.e. step_kernel / step_split_kernel with SAMPLE = false and
+    fractional-degree actions -- at every dispatch regime, every env against the C restatement of the reference
+    (manytor.py:255-260): the sampled-action tests above never run these instantiations at these sizes."""
+    from oracle import c_oracle
+    table = m.REF_DH_TABLE if table_name == "ref" else m.DH7_TABLE
+    radius = 51.3 if table_name == "ref" else 92.6
+    k, dof = 7, len(table)
+    rng = np.random.RandomState(n % 9973)
+    eng = m.StepEngine(n, k, dh_table=table, radius=radius)
+    if expect:
+        assert expect in eng.step_kernel_name(), eng.step_kernel_name()
+    ora = c_oracle.COracle(n, k, table=np.asarray(table), radius=radius, threads=16)
+    eng.reset_random(0xAC7, 0)
+    ora.reset(eng.points().astype(np.float64))
+    guarded_total = 0
+    for t in range(3):
+        # a policy's output: floats, some far outside [-180, 180), some tiny moves
+        act = rng.uniform(-200.0, 200.0, size=(n, dof)).astype(np.float32)
+        small = rng.rand(n) < 0.25
+        act[small] = (ora.goals[small] + rng.uniform(-2.0, 2.0, size=(int(small.sum()), dof))).astype(np.float32)
+        eng.step(act)
+        pre_alive = ora.alives.copy()
+        obs_ref, rew_ref, done_ref = ora.step(act.astype(np.float64))
+        np.testing.assert_array_equal(eng.goals(), act)                      # goals = action, manytor.py:184
+        assert np.abs(eng.joints_coordinates() - ora.joints_coordinates).max() <= POS_TOL
+        pm = np.where(pre_alive, ora.pickup_margin, np.inf).min(axis=1)
+        risky = (ora.ground_margin < GUARD) | (pm < GUARD)
+        ok = ~risky
+        guarded_total += int(risky.sum())
+        np.testing.assert_array_equal(eng.reward()[ok], rew_ref[ok])
+        np.testing.assert_array_equal(eng.done()[ok], done_ref[ok])
+        alive_gpu = eng.alives()
+        np.testing.assert_array_equal(alive_gpu[ok], ora.alives[ok])
+        assert_obs_close(eng.obs(), obs_ref, ora.joints_coordinates[:, -2], ora.points, pre_alive)
+        idx = np.flatnonzero(risky)                      # re-synchronise the few envs inside the guard band
+        ora.alive_u8[idx] = alive_gpu[idx]
+        ora.total_reward[idx] = eng.total_reward()[idx]
+        ora.points[idx] = eng.points()[idx].astype(np.float64)
+        np.testing.assert_array_equal(eng.total_reward(), ora.total_reward.astype(np.float32))
+    assert guarded_total < 3 * n * 3e-3 + 8, guarded_total
+    assert eng.bad_action_count() == 0
