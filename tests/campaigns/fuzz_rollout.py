@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised campaign over the SAMPLED-action paths (mt_reset_random / mt_rollout / mt_rollout_fused / mt_reset_done): random
-arm (reference, 7-joint, random table), joint count, targets, sub-steps (incl. > 26: per-pose sincos dispatch), batch size
+arm (reference, 7-joint, random table; sometimes with other observation / pickup rows), joint count, targets, sub-steps (incl. > 26: per-pose sincos dispatch), batch size
 (up to the sizes where mt_rollout runs as chains), and a random schedule forced through the environment -- MT_CHAINS 1..4,
 MT_GRAPH 0 / 1, MT_TRIG_TABLE 0 / 1, MT_SPLIT 0 / 2 / 4, MT_PREFETCH 0 / 1, MT_RESET_SPLIT 0 / 1.  Every case is checked two ways:
   * bit for bit against the plainest schedule of the same library (one chain, no graph, no table, one env per lane), all
@@ -56,6 +56,7 @@ while time.time() < deadline:
     if k == 32 and n > 100000:
         k = 7
     tol = float(rng.choice([3.0, 8.0, 25.0]))
+    frames = dict(obs_frame=int(rng.randint(-dof, dof)), ee_frame=int(rng.randint(1, dof))) if rng.rand() < 0.15 else {}
     seed = int(rng.randint(1, 1 << 30))
     plan = [(str(rng.choice(["rollout", "rollout", "fused", "fused_auto", "rollout_reset", "rollout_gather_reset"])), int(rng.randint(1, 12)))
             for _ in range(int(rng.randint(2, 6)))]
@@ -66,7 +67,8 @@ while time.time() < deadline:
     def run(env):
         for key in KNOBS:
             os.environ[key] = str(env[key])
-        e = m.StepEngine(n, k, dh_table=table, radius=radius, substeps=substeps, pickup_tol=tol, debug_zmin=True, return_ring=2)
+        e = m.StepEngine(n, k, dh_table=table, radius=radius, substeps=substeps, pickup_tol=tol, debug_zmin=True, return_ring=2,
+                         **frames)
         e.reset_random(seed, 3)
         p0 = e.points()
         t = 0
@@ -111,12 +113,12 @@ while time.time() < deadline:
     # step is the action of the step before it, whatever happened to the env earlier)
     act1 = px.sample_actions(seed, ids, total - 2, dof).astype(np.float64)
     act2 = px.sample_actions(seed, ids, total - 1, dof).astype(np.float64)
-    ora2 = c_oracle.COracle(n, k, table=table, radius=radius, substeps=substeps, pickup_tol=tol, threads=16)
+    ora2 = c_oracle.COracle(n, k, table=table, radius=radius, substeps=substeps, pickup_tol=tol, threads=16, **frames)
     ora2.reset(got["F_POINTS"].astype(np.float64))
     ora2.goals[:] = act1
     ora2.step(act2)
     ez = np.abs(got["F_ZMIN"] - ora2.zmin).max()
-    ee = np.abs(got["F_EE"] - ora2.joints_coordinates[:, -1]).max()
+    ee = np.abs(got["F_EE"] - ora2.joints_coordinates[:, frames.get("ee_frame", -1)]).max()
     gate = 1e-4 * max(1.0, radius / 92.6)            # the stated 1e-4 is for arms up to the 7-joint table's reach; longer random arms scale it
     assert ez <= gate and ee <= gate, (ez, ee, gate, knobs, n, k, dof, substeps)
     worst_z, worst_ee = max(worst_z, float(ez)), max(worst_ee, float(ee))
