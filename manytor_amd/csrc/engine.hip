@@ -566,11 +566,13 @@ int mt_create(mt_handle* out, const mt_config* cfg) {
   if (const char* env = std::getenv("MT_RESET_SPLIT")) h->reset_split = std::atoi(env) != 0;
   if (const char* env = std::getenv("MT_GRAPH")) h->graph_mode = std::atoi(env) != 0 ? 1 : 0;
   // mt_rollout as independent chains of launches on separate streams (engine_internal.h): MT_CHAINS = 1..4 overrides
-  // Two chains from 163 840 to 3 M envs (tools/chain_sweep.py --steady, tools/chain_variant_probe.py, profiles/r03_variants.md
-  // section 2: 8.45 -> 7.95 us per step at 163 840 envs, 10.5 -> 8.7 at 262 144, 21.5 -> 19.8 at 524 288, 39.9 -> 36.3 at 1 M,
-  // 74.6 -> 69.0 at 2 M; nothing at 4 M, where the launches are long and purely HBM-bound; at 131 072 envs = exactly two
-  // blocks per CU one launch is best (7.14 against 7.3-7.7), and below that the fork / join of every call costs more
-  // than the overlap returns, except at sizes that fill the CUs unevenly (98 304 envs: 7.1 -> 6.5) -- not special-cased).
+  // Two chains from 163 840 to 3 M envs (tools/chain_sweep.py --steady, tools/chain_variant_probe.py, tools/size_sweep.py,
+  // profiles/r03_variants.md section 2; us per step incl. the per-episode reset, one chain -> two): 163 840 envs 8.45 -> 7.15,
+  // 262 144 envs 10.5 -> 8.7, 524 288 envs 21.5 -> 19.8, 1 M envs 39.9 -> 36.3, 2 M envs 74.6 -> 69.0; nothing at 4 M, where
+  // the launches are long and purely HBM-bound.  At 98 304 .. 131 072 envs two chains of plain launches win 3-4 % in a long
+  // back-to-back run (131 072: 7.14 -> 6.85) but lose when a segment starts on an idle device, because the host then has
+  // to enqueue two launches per ~7 us step (131 072: 7.0 -> 7.4 us per step over a 50-step segment; 98 304: 7.0 -> 9.0):
+  // one chain and its cached graph stay the choice there.
   h->chains = (cfg->n_envs >= 163840 && cfg->n_envs <= 3145728) ? 2 : 1;
   if (const char* env = std::getenv("MT_CHAINS")) h->chains = std::max(1, std::min((int)mt_engine::kMaxChains, std::atoi(env)));
   if (cfg->n_envs < 2 * 256) h->chains = 1;
@@ -678,7 +680,10 @@ int mt_create(mt_handle* out, const mt_config* cfg) {
   h->chain_prefetch = h->prefetch;
   if (h->chains > 1) {
     const int64_t span = chain_span(h, h->chains);
-    h->chain_split = span <= 32768 ? 4 : (span <= 65536 ? 2 : 0);
+    // (two kernels of `span` envs are in flight, so the chip is as full as under one launch of 2 x span: the lane-split
+    // schedules stop paying earlier than for a lone batch -- chain_variant_probe.py: 2 x 65 536 envs 6.85 us per step with one
+    // env per lane against 7.0-7.35 with two lanes, 2 x 49 152 envs 6.8 with two lanes against 6.95 with one)
+    h->chain_split = span <= 16384 ? 4 : (span <= 49152 ? 2 : 0);
     h->chain_prefetch = span <= 131072;
     if (const char* env = std::getenv("MT_SPLIT")) {
       const int v = std::atoi(env);
@@ -1064,6 +1069,10 @@ int mt_bad_action_count(mt_handle h, uint64_t* count) {
 static bool rollout_uses_graph(mt_handle h, int n_steps) {
   if (h->graph_mode == 0 || h->trace || n_steps < 4) return false;
   if (h->graph_mode < 0 && h->n > 131072) return false;
+  // chains enqueue plain launches unless the graph is forced: a graph replay reads the segment's first step index from a
+  // device word that may only be rewritten once every chain has finished the previous segment, i.e. behind a join
+  // (131 072 envs: 6.85 us per step with plain launches, 7.4 with per-chain graphs)
+  if (h->graph_mode < 0 && h->chains > 1) return false;
   hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(h->stream, &st) != hipSuccess || st != hipStreamCaptureStatusNone) {
     (void)hipGetLastError();

@@ -19,8 +19,12 @@ def steady(n, env, episodes=12):
         e.reset_random(1, r); e.rollout(50, 1, 0)
     ms = e.timer_stop(); name = e.step_kernel_name(); e.close()
     return round(ms * 1e3 / (episodes * 50), 3), name
-for n in (98304, 131072, 163840):
-    for env in ({}, {"MT_CHAINS":"2","MT_GRAPH":"1"}, {"MT_CHAINS":"2","MT_GRAPH":"1","MT_SPLIT":"0"}, {"MT_CHAINS":"2","MT_GRAPH":"0","MT_SPLIT":"0"},
-                {"MT_CHAINS":"2","MT_GRAPH":"1","MT_SPLIT":"0","MT_PREFETCH":"0"}, {"MT_CHAINS":"3","MT_GRAPH":"1","MT_SPLIT":"0"}):
-        a = steady(n, env); b = steady(n, env)
+import sys as _sys
+sizes = [int(v) for v in _sys.argv[1:]] or [98304, 131072, 163840]
+for n in sizes:
+    for env in ({}, {"MT_CHAINS": "1"}, {"MT_CHAINS": "2", "MT_GRAPH": "0"}, {"MT_CHAINS": "2", "MT_GRAPH": "0", "MT_SPLIT": "0"},
+                {"MT_CHAINS": "2", "MT_GRAPH": "1"}, {"MT_CHAINS": "2", "MT_GRAPH": "1", "MT_SPLIT": "0"},
+                {"MT_CHAINS": "3", "MT_GRAPH": "0"}, {"MT_CHAINS": "3", "MT_GRAPH": "0", "MT_SPLIT": "0"}):
+        a = steady(n, env)
+        b = steady(n, env)
         print(n, env, a[0], b[0], a[1][-60:], flush=True)
