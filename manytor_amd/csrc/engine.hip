@@ -569,10 +569,10 @@ int mt_create(mt_handle* out, const mt_config* cfg) {
   // Two chains from 163 840 to 3 M envs (tools/chain_sweep.py --steady, tools/chain_variant_probe.py, tools/size_sweep.py,
   // profiles/r03_variants.md section 2; us per step incl. the per-episode reset, one chain -> two): 163 840 envs 8.45 -> 7.15,
   // 262 144 envs 10.5 -> 8.7, 524 288 envs 21.5 -> 19.8, 1 M envs 39.9 -> 36.3, 2 M envs 74.6 -> 69.0; nothing at 4 M, where
-  // the launches are long and purely HBM-bound.  At 98 304 .. 131 072 envs two chains of plain launches win 3-4 % in a long
-  // back-to-back run (131 072: 7.14 -> 6.85) but lose when a segment starts on an idle device, because the host then has
-  // to enqueue two launches per ~7 us step (131 072: 7.0 -> 7.4 us per step over a 50-step segment; 98 304: 7.0 -> 9.0):
-  // one chain and its cached graph stay the choice there.
+  // the launches are long and purely HBM-bound.  At 98 304 .. 131 072 envs two chains (with one cached graph per chain) win
+  // in a long back-to-back run (98 304: 7.1 -> 6.1 us per step, 131 072: 7.14 -> 6.98) but lose when a segment starts on an
+  // idle device (131 072: 7.0 -> 7.4-8.1 us per step over a 50-step segment: two graph launches and a fork against one
+  // graph launch): one chain and its cached graph stay the choice there.
   h->chains = (cfg->n_envs >= 163840 && cfg->n_envs <= 3145728) ? 2 : 1;
   if (const char* env = std::getenv("MT_CHAINS")) h->chains = std::max(1, std::min((int)mt_engine::kMaxChains, std::atoi(env)));
   if (cfg->n_envs < 2 * 256) h->chains = 1;
@@ -1069,10 +1069,7 @@ int mt_bad_action_count(mt_handle h, uint64_t* count) {
 static bool rollout_uses_graph(mt_handle h, int n_steps) {
   if (h->graph_mode == 0 || h->trace || n_steps < 4) return false;
   if (h->graph_mode < 0 && h->n > 131072) return false;
-  // chains enqueue plain launches unless the graph is forced: a graph replay reads the segment's first step index from a
-  // device word that may only be rewritten once every chain has finished the previous segment, i.e. behind a join
-  // (131 072 envs: 6.85 us per step with plain launches, 7.4 with per-chain graphs)
-  if (h->graph_mode < 0 && h->chains > 1) return false;
+
   hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(h->stream, &st) != hipSuccess || st != hipStreamCaptureStatusNone) {
     (void)hipGetLastError();
@@ -1083,7 +1080,8 @@ static bool rollout_uses_graph(mt_handle h, int n_steps) {
 
 // The cached graph(s) of a T-step segment: one graph per chain (chain c's T launches), to be replayed on chain c's stream.
 static int rollout_graph(mt_handle h, int T, uint64_t seed, int chains, const mt_engine::RolloutGraph** out) {
-  if (!h->graph_step0) MT_HIP(h, hipMalloc(&h->graph_step0, sizeof(uint32_t)));
+  // one word per chain: chain c's nodes read word c, which is rewritten on chain c's OWN stream right before its replay
+  if (!h->graph_step0) MT_HIP(h, hipMalloc(&h->graph_step0, sizeof(uint32_t) * mt_engine::kMaxChains));
   StepArgs a = h->args;
   a.seed_lo = (uint32_t)seed;
   a.seed_hi = (uint32_t)(seed >> 32);
@@ -1112,7 +1110,9 @@ static int rollout_graph(mt_handle h, int T, uint64_t seed, int chains, const mt
     MT_HIP(h, hipStreamBeginCapture(h->own_stream, hipStreamCaptureModeThreadLocal));
     h->stream = h->own_stream;
     if (chains > 1) {
-      launch_chain(h, a, 0u, T, chains, c);
+      StepArgs ac = a;
+      ac.major_base = h->graph_step0 + c;
+      launch_chain(h, ac, 0u, T, chains, c);
     } else {
       for (int s = 0; s < T; ++s) {
         StepArgs as = a;
@@ -1183,16 +1183,15 @@ int mt_rollout(mt_handle h, int n_steps, uint64_t seed, uint32_t step_idx0) {
     int rc = rollout_graph(h, n_steps, seed, chains, &rg);
     if (rc) return rc;
     if (chains > 1) {
-      // the word every node adds to its step offset is set on the handle's stream BEFORE the fork (while forked, by
-      // joining first: a chain may still be replaying the previous segment, which reads the same word)
-      rc = join_chains(h);
-      if (rc) return rc;
-      MT_HIP(h, hipMemsetD32Async((hipDeviceptr_t)h->graph_step0, (int)step_idx0, 1, h->stream));
       rc = fork_chains(h, chains);
       if (rc) return rc;
       const int64_t span = chain_span(h, chains);
-      for (int c = 0; c < chains; ++c)
-        if ((int64_t)c * span < h->n) MT_HIP(h, hipGraphLaunch(rg->exec[c], chain_stream(h, c)));
+      for (int c = 0; c < chains; ++c) {
+        if ((int64_t)c * span >= h->n) continue;
+        // chain c's step-index word is set on chain c's stream, behind its previous replay and ahead of this one
+        MT_HIP(h, hipMemsetD32Async((hipDeviceptr_t)(h->graph_step0 + c), (int)step_idx0, 1, chain_stream(h, c)));
+        MT_HIP(h, hipGraphLaunch(rg->exec[c], chain_stream(h, c)));
+      }
       rc = settle_chains(h);
       if (rc) return rc;
     } else {
