@@ -145,18 +145,26 @@ void launch_step_t(mt_handle h, const StepArgs& args, bool sample, bool whole_ro
   }
   if constexpr (ActionTrigTable<Tbl>::value) {
     if (tt) {
-      if (h->prefetch)
+      if (h->prefetch && args.n >= h->flat_from)  // HBM-bound launches: kernels.h, LaneOffset<false>
+        hipLaunchKernelGGL((step_kernel<Tbl, true, 0, false, kPrefetch, true, true>), g, b, 0, h->stream, args);
+      else if (h->prefetch)
         hipLaunchKernelGGL((step_kernel<Tbl, true, 0, false, kPrefetch, true>), g, b, 0, h->stream, args);
       else
         hipLaunchKernelGGL((step_kernel<Tbl, true, 0, false, 0, true>), g, b, 0, h->stream, args);
       return;
     }
   }
-  if (h->trig == 0 && h->prefetch) {  // small batches: target loads in flight before the kinematics (kernels.h, PF)
-    if (sample)
+  if (h->trig == 0 && h->prefetch) {  // target loads in flight before the kinematics (kernels.h, PF)
+    if (args.n >= h->flat_from) {
+      if (sample)
+        hipLaunchKernelGGL((step_kernel<Tbl, true, 0, false, kPrefetch, false, true>), g, b, 0, h->stream, args);
+      else
+        hipLaunchKernelGGL((step_kernel<Tbl, false, 0, false, kPrefetch, false, true>), g, b, 0, h->stream, args);
+    } else if (sample) {
       hipLaunchKernelGGL((step_kernel<Tbl, true, 0, false, kPrefetch>), g, b, 0, h->stream, args);
-    else
+    } else {
       hipLaunchKernelGGL((step_kernel<Tbl, false, 0, false, kPrefetch>), g, b, 0, h->stream, args);
+    }
     return;
   }
   switch (h->trig) {
@@ -577,6 +585,7 @@ int mt_create(mt_handle* out, const mt_config* cfg) {
   if (const char* env = std::getenv("MT_CHAINS")) h->chains = std::max(1, std::min((int)mt_engine::kMaxChains, std::atoi(env)));
   if (cfg->n_envs < 2 * 256) h->chains = 1;
   if (const char* env = std::getenv("MT_LAZY_CHAINS")) h->lazy_chains = std::atoi(env) != 0;  // 0: join at the end of every call
+  if (const char* env = std::getenv("MT_FLAT_FROM")) h->flat_from = std::max<long long>(0, std::atoll(env));
   h->prefetch_forced = false;
   if (const char* env = std::getenv("MT_PREFETCH")) {
     h->prefetch = std::atoi(env) != 0;
@@ -739,11 +748,13 @@ const char* mt_step_kernel_name(mt_handle h) {
   else
     h->kernel_name = "step_kernel<" + table + ", trig=" + std::to_string(h->trig) + ", lds=" + (h->lds_table ? "true" : "false") +
                      ", pf=" + ((h->trig == 0 && !h->lds_table && h->prefetch) ? std::to_string(kPrefetch) : std::string("0")) +
-                     ((h->trig == 0 && !h->lds_table && h->trig_steps) ? ", tt=1>" : ">");
+                     ((h->trig == 0 && !h->lds_table && h->trig_steps) ? ", tt=1" : "") +
+                     ((h->trig == 0 && !h->lds_table && h->prefetch && h->cfg.n_envs >= h->flat_from) ? ", flat=1>" : ">");
   if (h->chains > 1)  // what mt_rollout launches instead: the schedule for a chain's env count, on row views
     h->kernel_name += " [mt_rollout: " + std::to_string(h->chains) + " chains of " + std::to_string(chain_span(h, h->chains)) +
                       " envs, " + (h->trig == 0 && !h->lds_table && h->chain_split ? "L=" + std::to_string(h->chain_split)
-                                   : std::string(h->trig == 0 && !h->lds_table && h->chain_prefetch ? "pf=8" : "pf=0")) + "]";
+                                   : std::string(h->trig == 0 && !h->lds_table && h->chain_prefetch
+                                                     ? (chain_span(h, h->chains) >= h->flat_from ? "pf=8, flat=1" : "pf=8") : "pf=0")) + "]";
   return h->kernel_name.c_str();
 }
 

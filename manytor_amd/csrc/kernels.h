@@ -44,17 +44,44 @@ __device__ __forceinline__ global_ptr<char> uniform_row(const void* row) {
   const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
   return (global_ptr<char>)(((uint64_t)hi << 32) | lo);
 }
-template <typename T>
-__device__ __forceinline__ T ldr(const T* row, uint32_t boff) {
-  return *(global_ptr<const T>)(uniform_row(row) + boff);
+// The lane offset has to reach instruction selection as a 32-BIT value in the basic block of the access: selection works
+// per block, and an offset that was zero-extended once at the top and carried into other blocks as a 64-bit register can
+// no longer be proven to fit the `saddr + zext(voffset)` form -- every access then costs a v_lshl_add_u64 and a 64-bit
+// VGPR pair (96 of them in the prefetch kernel of the reference arm, 8 % of its instructions: round 3).  The empty asm
+// "redefines" the offset in place before every access -- the SAME register, no instruction -- so the extension is
+// re-materialised, and folded into the access, where it is used.  Hence the offset travels by reference: a kernel keeps
+// ONE variable per element size (o4 = 4 i for the 32-bit rows, o1 = i for the byte rows) and every accessor renews it.
+//   LaneOffset<true>  : renewed at every access (1 106 -> 1 013 VALU instructions in that kernel; 3-5 % less time where
+//                       the step is latency- or issue-bound: <= 262 144 envs, the 7-joint arm, the fused episodes)
+//   LaneOffset<false> : left to the optimiser (the 64-bit adds stay).  Where the reference arm's step is HBM-bound
+//                       (>= ~400 k envs per launch) THIS form is the faster one by 0.7-2 % -- same memory operations in
+//                       the same order, so the cause is the waves' timing against the memory system, not the code
+//                       (profiles/r03_variants.md section 8) -- and step_kernel's FLAT instantiation keeps it.
+#ifndef MT_PLAIN_LANE_OFFSET
+#define MT_PLAIN_LANE_OFFSET 0  // 1: no renewal anywhere (A/B builds: tools/ab_lane_offset.sh)
+#endif
+template <bool RENEW>
+struct LaneOffset {
+  uint32_t v;
+};
+template <bool RENEW>
+__device__ __forceinline__ uint32_t lane_offset(LaneOffset<RENEW>& o) {
+#if !MT_PLAIN_LANE_OFFSET
+  if (RENEW) asm volatile("" : "+v"(o.v));
+#endif
+  return o.v;
 }
-template <typename T>
-__device__ __forceinline__ void str(T* row, uint32_t boff, T v) {
-  *(global_ptr<T>)(uniform_row(row) + boff) = v;
+template <typename T, bool R>
+__device__ __forceinline__ T ldr(const T* row, LaneOffset<R>& o) {
+  return *(global_ptr<const T>)(uniform_row(row) + lane_offset(o));
 }
-template <typename T>
-__device__ __forceinline__ void str_stream(T* row, uint32_t boff, T v) {
-  global_ptr<T> p = (global_ptr<T>)(uniform_row(row) + boff);
+template <typename T, bool R>
+__device__ __forceinline__ void str(T* row, LaneOffset<R>& o, T v) {
+  *(global_ptr<T>)(uniform_row(row) + lane_offset(o)) = v;
+}
+template <typename T, bool R>
+__device__ __forceinline__ void str_stream(T* row, LaneOffset<R>& o, T v) {
+  global_ptr<T> p = (global_ptr<T>)(uniform_row(row) + lane_offset(o));
 #if MT_NT_STORES
   __builtin_nontemporal_store(v, p);
 #else
@@ -227,8 +254,8 @@ __device__ __forceinline__ bool within_box(const float (&e)[3], float x, float y
 
 // One target inside step(): obs2 triple (taken before the pickup, manytor.py:204), pickup test
 // (manytor.py:206), and the zeroing of a target that died earlier (manytor.py:148).
-template <bool ABLATE_OBS>
-__device__ __forceinline__ void step_target(const StepArgs& a, int64_t ld, uint32_t i, int k, uint32_t am, uint32_t& nam,
+template <bool ABLATE_OBS, bool R>
+__device__ __forceinline__ void step_target(const StepArgs& a, int64_t ld, LaneOffset<R>& o4, int k, uint32_t am, uint32_t& nam,
                                             const float (&el)[3], const float (&e)[3], float x, float y, float z) {
   const bool al = (am >> k) & 1u;
   float dist = 0.f, r = 0.f, th = 0.f;
@@ -243,14 +270,14 @@ __device__ __forceinline__ void step_target(const StepArgs& a, int64_t ld, uint3
     if (within_box(e, x, y, z, a.tol)) nam &= ~(1u << k);
   } else if ((x != 0.f) | (y != 0.f) | (z != 0.f)) {
     float* row = a.points + (int64_t)(3 * k) * ld;
-    str(row, i * 4u, 0.f);
-    str(row + ld, i * 4u, 0.f);
-    str(row + 2 * ld, i * 4u, 0.f);
+    str(row, o4, 0.f);
+    str(row + ld, o4, 0.f);
+    str(row + 2 * ld, o4, 0.f);
   }
   float* orow = a.obs + (int64_t)(3 * k) * ld;
-  str_stream(orow, i * 4u, dist);
-  str_stream(orow + ld, i * 4u, r);
-  str_stream(orow + 2 * ld, i * 4u, th);
+  str_stream(orow, o4, dist);
+  str_stream(orow + ld, o4, r);
+  str_stream(orow + 2 * ld, o4, th);
 }
 
 // ---------------------------------------------------------------------------
@@ -627,7 +654,8 @@ __device__ __forceinline__ float route_kinematics(const Tbl& t, int S, float inv
 // An env finished its episode `episode` with return `ret` and is being re-armed: keep the return in the ring
 // (slot = number of episodes it finished before, modulo the ring size) and in the one-slot last_return row.
 __device__ __forceinline__ void record_finished(const StepArgs& a, uint32_t i, uint32_t episode, float ret) {
-  str(a.last_return, i * 4u, ret);
+  LaneOffset<true> o4{i * 4u};
+  str(a.last_return, o4, ret);
   if (a.ring_slots)  // the slot differs from lane to lane: plain per-lane addressing, not a uniform row
     a.ring[(int64_t)((episode - a.episode0) % a.ring_slots) * a.ld + i] = ret;
 }
@@ -675,7 +703,8 @@ constexpr int kPrefetch = 8;
 //            (most where an env is spread over lanes and the end poses are replicated; profiles/r03_variants.md section 3).
 //            Whole batch or a 256-aligned range of it only (threads past the end run up to the barrier: their loads stay
 //            inside the rows, which are ld >= round_up(n, 256) long); same bits as the computed values.
-template <class Tbl, bool SAMPLE, int TRIG, bool LDS, int PF = 0, bool TT = false>
+//   FLAT   : the rows are addressed through LaneOffset<false> (see there): the HBM-bound launches of the prefetch kernel.
+template <class Tbl, bool SAMPLE, int TRIG, bool LDS, int PF = 0, bool TT = false, bool FLAT = false>
 __global__ __launch_bounds__(kBlock, (PF ? 1 : step_min_waves<Tbl, TRIG>())) void step_kernel(const StepArgs a) {
   constexpr int D = Tbl::D;
   static_assert(!TT || (SAMPLE && TRIG == 0 && !LDS && ActionTrigTable<Tbl>::value), "the table serves sampled actions of a static table");
@@ -692,8 +721,13 @@ __global__ __launch_bounds__(kBlock, (PF ? 1 : step_min_waves<Tbl, TRIG>())) voi
   const Tbl t = TableMaker<Tbl>::make(LDS ? sh : a.dh);
 
   const uint32_t i = blockIdx.x * kBlock + threadIdx.x;  // 32-bit lane offset: rows are addressed as uniform base + i
+  LaneOffset<!FLAT> o4{i * 4u}, o1{i};  // byte offsets of this lane in the 32-bit rows / the byte rows
   if (!TT && i >= a.n) return;
   const int64_t ld = a.ld;
+  // Read ahead of every row access: behind one (its lane offset renewal is an opaque asm to the memory analysis) the
+  // word is no longer provably unclobbered, and the s_load turns into a vector load with an s_waitcnt vmcnt(0) behind
+  // it -- which also waits for every prefetched row (measured: +2 % per step at 1 M envs under graph replay).
+  const uint32_t step_no = SAMPLE ? step_index(a) : 0u;
 
   // Long arms (D >= 6) are register-bound: their kernel keeps nothing alive across the sub-step loops that it can
   // fetch or store on the other side of them (alive mask and return loaded after, new goals stored before).
@@ -701,7 +735,7 @@ __global__ __launch_bounds__(kBlock, (PF ? 1 : step_min_waves<Tbl, TRIG>())) voi
   MT_STAMP(a, i, 0);
   float g[D], act[D];
 #pragma unroll
-  for (int j = 0; j < D; ++j) g[j] = ldr(a.goals + j * ld, i * 4u);
+  for (int j = 0; j < D; ++j) g[j] = ldr(a.goals + j * ld, o4);
   float tx[PF ? PF : 1][3];
   if (PF) {
 #pragma unroll
@@ -709,7 +743,7 @@ __global__ __launch_bounds__(kBlock, (PF ? 1 : step_min_waves<Tbl, TRIG>())) voi
       if (k < a.K) {
         const float* row = a.points + (int64_t)(3 * k) * ld;
 #pragma unroll
-        for (int q = 0; q < 3; ++q) tx[k][q] = ldr(row + q * ld, i * 4u);
+        for (int q = 0; q < 3; ++q) tx[k][q] = ldr(row + q * ld, o4);
       }
   }
   // The alive mask and the return are requested now, ahead of the arithmetic that does not need them.
@@ -717,17 +751,17 @@ __global__ __launch_bounds__(kBlock, (PF ? 1 : step_min_waves<Tbl, TRIG>())) voi
   uint32_t am = 0;
   float total_in = 0.f;
   if (!kLean || PF) {
-    am = ldr(a.alive, i * 4u);
-    total_in = ldr(a.total_reward, i * 4u);
+    am = ldr(a.alive, o4);
+    total_in = ldr(a.total_reward, o4);
   }
   if (SAMPLE) {
     // not stored separately: the action taken becomes `goals` below (manytor.py:184), 4D bytes of traffic saved
-    draw_action<D>(((uint64_t)a.seed_hi << 32) | a.seed_lo, (uint64_t)(a.env_base + i), step_index(a), act);
+    draw_action<D>(((uint64_t)a.seed_hi << 32) | a.seed_lo, (uint64_t)(a.env_base + i), step_no, act);
   } else {
     bool bad = false;
 #pragma unroll
     for (int j = 0; j < D; ++j) {
-      act[j] = ldr(a.actions + j * ld, i * 4u);
+      act[j] = ldr(a.actions + j * ld, o4);
       bad |= unusable_angle(act[j]);
     }
     if (bad) {  // the env holds its pose this step; the call is counted (mt_bad_action_count)
@@ -743,17 +777,17 @@ __global__ __launch_bounds__(kBlock, (PF ? 1 : step_min_waves<Tbl, TRIG>())) voi
   }
   if (kLean) {  // goals = action (manytor.py:184): the old pose is in registers already
 #pragma unroll
-    for (int j = 0; j < D; ++j) str(a.goals + j * ld, i * 4u, act[j]);
+    for (int j = 0; j < D; ++j) str(a.goals + j * ld, o4, act[j]);
   }
 
   float el[3], e[3];
   const float zmin = route_kinematics<Tbl, TRIG, false, TT>(t, a.S, a.inv_sm1, g, act, el, e, nullptr, false, trig_lds,
                                                             (a.flags & kFlagWholeGoals) != 0);
   const bool ground = zmin < 0.f;  // manytor.py:191
-  if (a.zmin) str_stream(a.zmin, i * 4u, zmin);  // MT_FLAG_DEBUG_ZMIN: wave-uniform branch on an SGPR pointer, NULL by default
+  if (a.zmin) str_stream(a.zmin, o4, zmin);  // MT_FLAG_DEBUG_ZMIN: wave-uniform branch on an SGPR pointer, NULL by default
   if (kLean && !PF) {
-    am = ldr(a.alive, i * 4u);
-    total_in = ldr(a.total_reward, i * 4u);
+    am = ldr(a.alive, o4);
+    total_in = ldr(a.total_reward, o4);
   }
   MT_STAMP(a, i, 2);  // kinematics done (this waits for the pose loads)
 
@@ -762,7 +796,7 @@ __global__ __launch_bounds__(kBlock, (PF ? 1 : step_min_waves<Tbl, TRIG>())) voi
   if (PF) {
 #pragma unroll
     for (int k = 0; k < PF; ++k)
-      if (k < a.K) step_target<false>(a, ld, i, k, am, nam, el, e, tx[k][0], tx[k][1], tx[k][2]);
+      if (k < a.K) step_target<false>(a, ld, o4, k, am, nam, el, e, tx[k][0], tx[k][1], tx[k][2]);
   }
   for (int k = PF; k < a.K; ++k) {
     if (TRIG == 5) {  // DIAGNOSTIC: arithmetic only, no HBM traffic for targets / observations
@@ -774,7 +808,10 @@ __global__ __launch_bounds__(kBlock, (PF ? 1 : step_min_waves<Tbl, TRIG>())) voi
       continue;
     }
     const float* row = a.points + (int64_t)(3 * k) * ld;
-    step_target<TRIG == 4>(a, ld, i, k, am, nam, el, e, ldr(row, i * 4u), ldr(row + ld, i * 4u), ldr(row + 2 * ld, i * 4u));
+    {
+      const float x = ldr(row, o4), y = ldr(row + ld, o4), z = ldr(row + 2 * ld, o4);
+      step_target<TRIG == 4>(a, ld, o4, k, am, nam, el, e, x, y, z);
+    }
   }
 
   MT_STAMP(a, i, 3);  // target loop done
@@ -784,14 +821,14 @@ __global__ __launch_bounds__(kBlock, (PF ? 1 : step_min_waves<Tbl, TRIG>())) voi
 
   if (!kLean) {
 #pragma unroll
-    for (int j = 0; j < D; ++j) str(a.goals + j * ld, i * 4u, act[j]);
+    for (int j = 0; j < D; ++j) str(a.goals + j * ld, o4, act[j]);
   }
 #pragma unroll
-  for (int q = 0; q < 3; ++q) str_stream(a.ee + q * ld, i * 4u, e[q]);
-  str(a.alive, i * 4u, nam);
-  str_stream(a.reward, i * 4u, rew);
-  str(a.total_reward, i * 4u, total_in + (float)rew);  // manytor.py:258
-  str_stream(a.done, i, (uint8_t)(done ? 1 : 0));
+  for (int q = 0; q < 3; ++q) str_stream(a.ee + q * ld, o4, e[q]);
+  str(a.alive, o4, nam);
+  str_stream(a.reward, o4, rew);
+  str(a.total_reward, o4, total_in + (float)rew);  // manytor.py:258
+  str_stream(a.done, o1, (uint8_t)(done ? 1 : 0));
   const unsigned long long bits = __ballot(done);
   if ((threadIdx.x & 63) == 0) a.done_bits[i >> 6] = bits;
   MT_STAMP(a, i, 4);  // all stores issued
@@ -1030,19 +1067,21 @@ __global__ __launch_bounds__(kBlock) void step_split_kernel(const StepArgs a) {
 template <int D, bool SAMPLE>
 __global__ __launch_bounds__(kBlock) void trace_kernel(const StepArgs a, float* trace) {
   const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  LaneOffset<true> o4{i * 4u};
   if (i >= a.n) return;
   const int64_t ld = a.ld;
   const RtTableF<D> t{a.dh};
+  const uint32_t step_no = SAMPLE ? step_index(a) : 0u;  // ahead of the row accesses: see step_kernel
   float g[D], act[D], st[D];
 #pragma unroll
-  for (int j = 0; j < D; ++j) g[j] = ldr(a.goals + j * ld, i * 4u);
+  for (int j = 0; j < D; ++j) g[j] = ldr(a.goals + j * ld, o4);
   if (SAMPLE) {
-    draw_action<D>(((uint64_t)a.seed_hi << 32) | a.seed_lo, (uint64_t)(a.env_base + i), step_index(a), act);
+    draw_action<D>(((uint64_t)a.seed_hi << 32) | a.seed_lo, (uint64_t)(a.env_base + i), step_no, act);
   } else {
     bool bad = false;
 #pragma unroll
     for (int j = 0; j < D; ++j) {
-      act[j] = ldr(a.actions + j * ld, i * 4u);
+      act[j] = ldr(a.actions + j * ld, o4);
       bad |= unusable_angle(act[j]);
     }
     if (bad) {
@@ -1063,7 +1102,7 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(const StepArgs a, float* 
     float el[3], e[3];
     pick_frames<RtTableF<D>>(t, p, el, e);
 #pragma unroll
-    for (int q = 0; q < 3; ++q) str_stream(trace + (int64_t)(3 * k + q) * ld, i * 4u, e[q]);
+    for (int q = 0; q < 3; ++q) str_stream(trace + (int64_t)(3 * k + q) * ld, o4, e[q]);
   }
 }
 
@@ -1395,6 +1434,7 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(const StepArgs a, const
     trig = w;
   }
   const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  LaneOffset<true> o4{i * 4u}, o1{i};
   if (i >= a.n) return;  // no barrier below: every thread touches only its own LDS column
   const int64_t ld = a.ld;
   const uint64_t seed = ((uint64_t)a.seed_hi << 32) | a.seed_lo;
@@ -1403,12 +1443,12 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(const StepArgs a, const
 
   float g[D];
 #pragma unroll
-  for (int j = 0; j < D; ++j) g[j] = ldr(a.goals + j * ld, i * 4u);
-  uint32_t am = ldr(a.alive, i * 4u);
-  float total = ldr(a.total_reward, i * 4u);
-  uint32_t episode = r.auto_reset ? ldr(a.episodes, i * 4u) : 0u;
+  for (int j = 0; j < D; ++j) g[j] = ldr(a.goals + j * ld, o4);
+  uint32_t am = ldr(a.alive, o4);
+  float total = ldr(a.total_reward, o4);
+  uint32_t episode = r.auto_reset ? ldr(a.episodes, o4) : 0u;
   bool ended = false, dirty = false;
-  for (int k = 0; k < 3 * a.K; ++k) col[k * kBlock] = ldr(a.points + (int64_t)k * ld, i * 4u);
+  for (int k = 0; k < 3 * a.K; ++k) col[k * kBlock] = ldr(a.points + (int64_t)k * ld, o4);
   const uint32_t all_alive = (a.K >= 32) ? 0xFFFFFFFFu : ((1u << a.K) - 1u);
   PoseCache<D> pose;        // sines / cosines and frame heights of the pose the next step starts from
   bool pose_valid = false;  // nothing known about the pose loaded from memory
@@ -1420,7 +1460,7 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(const StepArgs a, const
                                                               (a.flags & kFlagWholeGoals) != 0 || s > 0);
     pose_valid = true;
     const bool ground = zmin < 0.f;
-    if (a.zmin) str_stream(a.zmin, i * 4u, zmin);  // MT_FLAG_DEBUG_ZMIN (a step output like reward: the last step's stays)
+    if (a.zmin) str_stream(a.zmin, o4, zmin);  // MT_FLAG_DEBUG_ZMIN (a step output like reward: the last step's stays)
 
     uint32_t nam = am;
     for (int k = 0; k < a.K; ++k) {
@@ -1438,9 +1478,9 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(const StepArgs a, const
         dirty = true;
       }
       float* orow = a.obs + (int64_t)(3 * k) * ld;
-      str_stream(orow, i * 4u, dist);
-      str_stream(orow + ld, i * 4u, rr);
-      str_stream(orow + 2 * ld, i * 4u, th);
+      str_stream(orow, o4, dist);
+      str_stream(orow + ld, o4, rr);
+      str_stream(orow + 2 * ld, o4, th);
     }
     const int32_t rew = ground ? -1 : ((nam != am) ? 1 : 0);
     bool done = (nam == 0u);
@@ -1450,10 +1490,10 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(const StepArgs a, const
 #pragma unroll
     for (int j = 0; j < D; ++j) g[j] = act[j];
 #pragma unroll
-    for (int q = 0; q < 3; ++q) str_stream(a.ee + q * ld, i * 4u, e[q]);
-    str_stream(a.reward, i * 4u, rew);
+    for (int q = 0; q < 3; ++q) str_stream(a.ee + q * ld, o4, e[q]);
+    str_stream(a.reward, o4, rew);
     // 2 = "finished in this step and already re-armed below": mt_reset_done must not re-arm it a second time
-    str_stream(a.done, i, (uint8_t)(done ? (r.auto_reset ? 2 : 1) : 0));
+    str_stream(a.done, o1, (uint8_t)(done ? (r.auto_reset ? 2 : 1) : 0));
     const unsigned long long bits = __ballot(done);
     if ((threadIdx.x & 63) == 0) a.done_bits[i >> 6] = bits;
 
@@ -1477,12 +1517,12 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(const StepArgs a, const
   }
 
 #pragma unroll
-  for (int j = 0; j < D; ++j) str(a.goals + j * ld, i * 4u, g[j]);
-  str(a.alive, i * 4u, am);
-  str(a.total_reward, i * 4u, total);
-  if (ended) str(a.episodes, i * 4u, episode);
+  for (int j = 0; j < D; ++j) str(a.goals + j * ld, o4, g[j]);
+  str(a.alive, o4, am);
+  str(a.total_reward, o4, total);
+  if (ended) str(a.episodes, o4, episode);
   if (dirty)
-    for (int k = 0; k < 3 * a.K; ++k) str(a.points + (int64_t)k * ld, i * 4u, col[k * kBlock]);
+    for (int k = 0; k < 3 * a.K; ++k) str(a.points + (int64_t)k * ld, o4, col[k * kBlock]);
 }
 
 // rollout with one env spread over L lanes (L = 2 or 4): rollout_kernel for batches so small that a step's time is one

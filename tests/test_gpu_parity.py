@@ -1150,6 +1150,37 @@ def test_rollout_in_independent_chains_equals_plain_launches(m, monkeypatch, n, 
         np.testing.assert_array_equal(e.get(getattr(m.lib, f)), ref.get(getattr(m.lib, f)), err_msg=f)
 
 
+@pytest.mark.parametrize("sampled", [True, False])
+@pytest.mark.parametrize("n,k,table_name", [(100003, 7, "ref"), (262144, 3, "ref"), (70001, 7, "dh7"), (999, 9, "ref")])
+def test_flat_row_addressing_equals_renewed_lane_offsets(m, monkeypatch, n, k, table_name, sampled):
+    """The prefetch kernel exists in two addressing forms (kernels.h, LaneOffset<true | false>; the host takes the FLAT one
+    from MT_FLAT_FROM envs per launch, default 393 216: the HBM-bound launches).  Same arithmetic, same memory operations:
+    every field equal bit for bit, sampled (TT) and staged actions, ragged sizes, more targets than prefetch slots."""
+    table = m.REF_DH_TABLE if table_name == "ref" else m.DH7_TABLE
+    radius = 51.3 if table_name == "ref" else 92.6
+    fields = STATE_FIELDS + STEP_FIELDS
+    monkeypatch.setenv("MT_SPLIT", "0")
+    monkeypatch.setenv("MT_PREFETCH", "1")
+    monkeypatch.setenv("MT_CHAINS", "1")
+    got = {}
+    for flat_from in (0, 1 << 40):
+        monkeypatch.setenv("MT_FLAT_FROM", str(flat_from))
+        e = m.StepEngine(n, k, dh_table=table, radius=radius, pickup_tol=20.0)
+        name = e.step_kernel_name()
+        assert "pf=8" in name and ("flat=1" in name) == (flat_from == 0), name
+        e.reset_random(11, 0)
+        if sampled:
+            e.rollout(7, 11, 0)
+        else:
+            rng = np.random.RandomState(5)
+            for _ in range(3):
+                e.step(rng.uniform(-190.0, 190.0, size=(n, e.dof)).astype(np.float32))
+        got[flat_from] = {f: e.get(getattr(m.lib, f)) for f in fields}
+        e.close()
+    for f in fields:
+        np.testing.assert_array_equal(got[0][f], got[1 << 40][f], err_msg=f)
+
+
 @pytest.mark.parametrize("table_name", ["ref", "dh7"])
 @pytest.mark.parametrize("n,expect", [(32768, "L=4"), (65536, "L=2"), (131072, "pf=8"), (1048576, None)])
 def test_staged_action_step_every_env_against_the_c_oracle(m, table_name, n, expect):
