@@ -13,8 +13,9 @@ over the ranks (mt_gather_returns: RCCL all-gather straight from the arena, the 
 all envs are reset (test_multi.py:32-34).
 
 Timing protocol (robust to short --steps; `measure()`): a time-based pre-warm brings the GPU to its steady clock, then W
-untimed warm-up steps, the running episode is ended so that a region starts an episode, then the region of EXACTLY K steps
--- bracketed by barrier + torch.cuda.synchronize() on both sides, max over ranks -- is run `repeats` times; `ms_per_step` /
+untimed warm-up steps, the running episode is ended so that a region starts an episode (N = 1) or half-way through one (N > 1:
+the region's RCCL exchange then runs beside the steps behind the episode end; --episode-phase), then the region of EXACTLY K
+steps -- bracketed by barrier + torch.cuda.synchronize() on both sides, max over ranks -- is run `repeats` times; `ms_per_step` /
 `value` come from the MEDIAN region (min / max beside it).  The device time of a step is measured with HIP events on the
 engine's stream around the step launches of every region (mt_rollout may run a step as two concurrent launches on two
 streams, forked from and joined to that stream inside the laps; `roofline` says so).
@@ -224,14 +225,19 @@ class EpisodeLoop:
         self._bufs = [None, None]
         self.eng.reset_random(seed, 0)
 
+    phase = 0                   # steps of the running episode already done when a timed region starts (--episode-phase)
+
     def align(self):
         """End the running episode now (gather + reset, as at a regular episode end), so that the next step is the first of
-        an episode.  bench.measure() calls it between the untimed warm-up steps and the first timed region: a region of
-        K = episode_len steps is then ONE rollout segment followed by its gather and reset, not two segments around an
-        episode boundary left wherever the warm-up happened to stop."""
+        an episode, then run `phase` steps of it.  bench.measure() calls it between the untimed warm-up steps and the first
+        timed region.  phase = 0: a region of K = episode_len steps is ONE rollout segment followed by its gather and reset
+        (the exchange then runs beside the reset only, and the fence waits for it).  phase = p: every region is the last
+        L - p steps of an episode, its gather and reset, and the first p steps of the next one beside the exchange."""
         if self.step % self.L:
             self.step += self.L - self.step % self.L
             self._episode_end(False)
+        if self.phase % self.L:
+            self.run(self.phase % self.L)
 
     def _episode_end(self, time_kernels):
         """test_multi.py:32-34: read every env's return, then reset every env.  Overlapped form: the returns are
@@ -490,6 +496,12 @@ def main():
     ap.add_argument("--reset-before-gather", action="store_true",
                     help="experiment: at an episode end reset first, then gather MT_F_LAST_RETURN in place (no snapshot copy) "
                          "instead of snapshot + gather, then reset")
+    ap.add_argument("--episode-phase", type=int, default=-1,
+                    help="steps of the running episode already done when a timed region starts (0: every region is one "
+                         "whole segment and ends with its gather + reset; p: the episode ends L - p steps into the region "
+                         "and the exchange runs beside the p steps behind it).  Default: 0 on one GPU (nothing to hide: "
+                         "40.9 vs 42.0 us per step, profiles/r03_ab_episode_phase.txt), half an episode with N > 1 (the "
+                         "RCCL all-gather of a region is then hidden behind steps instead of waited for at the fence)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
@@ -530,6 +542,7 @@ def main():
     from manytor_amd import distributed as D
 
     EpisodeLoop.reset_first = args.reset_before_gather
+    EpisodeLoop.phase = args.episode_phase if args.episode_phase >= 0 else (0 if args.gpus == 1 else min(args.episode_len, args.steps) // 2)
     rank, local_rank, world = D.env_from_torchrun()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
@@ -630,7 +643,7 @@ def main():
                 "ms_per_step_min": r["ms_per_step_min"], "ms_per_step_max": r["ms_per_step_max"],
                 "avg_kernel_us": r["step_us"], "kernel": name, "gather_us": r["gather_us"],
                 "gathers_in_timed_region": r["gathers_per_region"], "repeats": r["repeats"], "episode_len": r["episode_len"],
-                "collective": describe_collective(fallback), "gather_mode": gather_mode(fallback),
+                "episode_phase": EpisodeLoop.phase % r["episode_len"], "collective": describe_collective(fallback), "gather_mode": gather_mode(fallback),
                 # per-GPU fraction of the HBM peak while a step is on the device
                 "frac_of_hbm_peak_per_gpu": bpe_actual * n_local / (r["step_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
                 "bytes_per_env_step": bpe_actual,
@@ -675,7 +688,8 @@ def main():
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": workload, "envs_per_gpu": n_local, "envs_total": n_total, "dof": args.dof,
-                       "targets": args.targets, "substeps": 25, "episode_len": L, "collective": describe_collective(gather_fallback),
+                       "targets": args.targets, "substeps": 25, "episode_len": L, "episode_phase": EpisodeLoop.phase % L,
+                       "collective": describe_collective(gather_fallback),
                        "kernel_variant": variant, "prewarm_launches": r["prewarm"], "repeats": r["repeats"],
                        "gathers_in_timed_region": r["gathers_per_region"], "gather_mode": gather_mode(gather_fallback),
                        "timing": "median over `repeats` regions of exactly `steps` steps, each bracketed by barrier + "
