@@ -619,16 +619,21 @@ __device__ __forceinline__ float route_kinematics(const Tbl& t, int S, float inv
     cB[0] = 1.f;
     const int nf = (S - 1) / 2;   // forward poses k = 1..nf
     const int nb = S - 2 - nf;    // backward poses k = S-2..nf+1   (nb = nf or nf-1)
+    // both halves advance together for nb iterations (no condition inside the loop: the two chains' registers stay where
+    // they are), then the forward half's extra pose when the number of interior poses is odd
 #pragma unroll 2
-    for (int it = 1; it <= nf; ++it) {
+    for (int it = 1; it <= nb; ++it) {
       rotate_pose<D, JN, +1>(sF, cF, sd, cd);
       chain_z<Tbl>(sF, cF, t, zo, ze);
       zmin = fminf(zmin, fminf(zo, ze));
-      if (it <= nb) {
-        rotate_pose<D, JN, -1>(sB, cB, sd, cd);
-        chain_z<Tbl>(sB, cB, t, zo, ze);
-        zmin = fminf(zmin, fminf(zo, ze));
-      }
+      rotate_pose<D, JN, -1>(sB, cB, sd, cd);
+      chain_z<Tbl>(sB, cB, t, zo, ze);
+      zmin = fminf(zmin, fminf(zo, ze));
+    }
+    if (nf > nb) {
+      rotate_pose<D, JN, +1>(sF, cF, sd, cd);
+      chain_z<Tbl>(sF, cF, t, zo, ze);
+      zmin = fminf(zmin, fminf(zo, ze));
     }
   } else {
     float gq[D];
