@@ -8,6 +8,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <cstdint>
+
 namespace mt {
 
 // Every kernel is compiled with -ffp-contract=off and spells its fused multiply-adds out, so that a formula
@@ -44,20 +46,34 @@ __device__ __forceinline__ float pfma(float a, float b, float c) {
   return __builtin_fmaf(a, b, c);
 }
 
+// a * b + K for a compile-time K, as ONE instruction wherever it is inlined (v_fmaak_f32: the addend is a literal of the
+// instruction).  Left to the compiler, a Horner chain whose coefficients are used twice in a block -- the two atan of an
+// observation, the sin and cos polynomials of two poses -- keeps the literals only in the first chain: the second gets a
+// v_mov_b32 of the coefficient plus a v_fmac_f32, two issue slots per term (49 extra instructions per wave-step in the
+// reference arm's step kernel).  Same operation (a fused multiply-add, round once), hence the same bits as __builtin_fmaf.
+template <uint32_t KBITS>
+__device__ __forceinline__ float fma_lit(float a, float b) {
+  if (__builtin_constant_p(a) && __builtin_constant_p(b)) return __builtin_fmaf(a, b, __builtin_bit_cast(float, KBITS));
+  float r;
+  asm("v_fmaak_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "n"(KBITS));
+  return r;
+}
+#define MT_FMA_LIT(a, b, K) ::mt::fma_lit<__builtin_bit_cast(uint32_t, (float)(K))>((a), (b))
+
 // sin and cos of x degrees, |x| <= 720 or so.  Max abs error ~8e-8.
 __device__ __forceinline__ void sincos_deg(float x, float& s, float& c) {
   const float q = __builtin_rintf(x * (1.0f / 90.0f));
   const float f = __builtin_fmaf(q, -90.0f, x);  // exact: |f| <= 45
   const float z = f * f;
   float ps = -9.621979952e-17f;
-  ps = __builtin_fmaf(ps, z, 1.349391605e-11f);
-  ps = __builtin_fmaf(ps, z, -8.860952789e-07f);
-  ps = __builtin_fmaf(ps, z, 1.745329238e-02f);
+  ps = MT_FMA_LIT(ps, z, 1.349391605e-11f);
+  ps = MT_FMA_LIT(ps, z, -8.860952789e-07f);
+  ps = MT_FMA_LIT(ps, z, 1.745329238e-02f);
   ps *= f;
   float pc = 2.099184062e-19f;
-  pc = __builtin_fmaf(pc, z, -3.925190319e-14f);
-  pc = __builtin_fmaf(pc, z, 3.866319265e-09f);
-  pc = __builtin_fmaf(pc, z, -1.523087121e-04f);
+  pc = MT_FMA_LIT(pc, z, -3.925190319e-14f);
+  pc = MT_FMA_LIT(pc, z, 3.866319265e-09f);
+  pc = MT_FMA_LIT(pc, z, -1.523087121e-04f);
   pc = __builtin_fmaf(pc, z, 1.0f);
   const int qi = (int)q;
   // quadrant rotation: (s,c) -> q&1 ? (c,-s) : (s,c); q&2 ? negate both
@@ -89,13 +105,13 @@ __device__ __forceinline__ float atan2_deg_q1(float y, float x) {
   const float w = q * q;
   // atan(q)/q on [0,1], already scaled to degrees (tools/gen_poly.py ATAN x 180/pi)
   float p = -4.668773152e-03f * 57.29577951308232f;
-  p = __builtin_fmaf(p, w, 2.416618913e-02f * 57.29577951308232f);
-  p = __builtin_fmaf(p, w, -5.936710164e-02f * 57.29577951308232f);
-  p = __builtin_fmaf(p, w, 9.906096756e-02f * 57.29577951308232f);
-  p = __builtin_fmaf(p, w, -1.401658505e-01f * 57.29577951308232f);
-  p = __builtin_fmaf(p, w, 1.996923536e-01f * 57.29577951308232f);
-  p = __builtin_fmaf(p, w, -3.333196044e-01f * 57.29577951308232f);
-  p = __builtin_fmaf(p, w, 9.999998808e-01f * 57.29577951308232f);
+  p = MT_FMA_LIT(p, w, 2.416618913e-02f * 57.29577951308232f);
+  p = MT_FMA_LIT(p, w, -5.936710164e-02f * 57.29577951308232f);
+  p = MT_FMA_LIT(p, w, 9.906096756e-02f * 57.29577951308232f);
+  p = MT_FMA_LIT(p, w, -1.401658505e-01f * 57.29577951308232f);
+  p = MT_FMA_LIT(p, w, 1.996923536e-01f * 57.29577951308232f);
+  p = MT_FMA_LIT(p, w, -3.333196044e-01f * 57.29577951308232f);
+  p = MT_FMA_LIT(p, w, 9.999998808e-01f * 57.29577951308232f);
   const float a = p * q;  // degrees, in [0, 45]
   return (y > x) ? 90.0f - a : a;
 }
@@ -106,14 +122,14 @@ __device__ __forceinline__ float atan2_deg_q1(float y, float x) {
 __device__ __forceinline__ void sincos_deg_small(float f, float& s, float& c) {
   const float z = f * f;
   float ps = -9.621979952e-17f;
-  ps = __builtin_fmaf(ps, z, 1.349391605e-11f);
-  ps = __builtin_fmaf(ps, z, -8.860952789e-07f);
-  ps = __builtin_fmaf(ps, z, 1.745329238e-02f);
+  ps = MT_FMA_LIT(ps, z, 1.349391605e-11f);
+  ps = MT_FMA_LIT(ps, z, -8.860952789e-07f);
+  ps = MT_FMA_LIT(ps, z, 1.745329238e-02f);
   s = ps * f;
   float pc = 2.099184062e-19f;
-  pc = __builtin_fmaf(pc, z, -3.925190319e-14f);
-  pc = __builtin_fmaf(pc, z, 3.866319265e-09f);
-  pc = __builtin_fmaf(pc, z, -1.523087121e-04f);
+  pc = MT_FMA_LIT(pc, z, -3.925190319e-14f);
+  pc = MT_FMA_LIT(pc, z, 3.866319265e-09f);
+  pc = MT_FMA_LIT(pc, z, -1.523087121e-04f);
   c = __builtin_fmaf(pc, z, 1.0f);
 }
 
