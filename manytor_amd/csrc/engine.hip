@@ -551,13 +551,14 @@ int mt_create(mt_handle* out, const mt_config* cfg) {
   h->lds_table = (cfg->flags & MT_FLAG_DH_IN_LDS) != 0 && !long_route;  // the LDS-table variant exists for the recurrence only
   // Which step kernel for which batch (tools/variant_sweep.py, profiles/r02_variants.md section 3; all variants give
   // the same bits):
-  //   <= 32 768 arms   one env over 4 lanes   (4.2-5.0 us per step against 5.6-6.2)
-  //   <= 65 536        one env over 2 lanes   (5.8-5.9 against 6.2-6.4)
+  //   <= 49 152 arms   one env over 4 lanes   (4.5-5.5 us per step against 5.3-5.9 with prefetch; at 49 152: 5.47 against
+  //                    5.70 with 2 lanes -- profiles/r03_variant_sweep_final.json)
+  //   <= 65 536        one env over 2 lanes   (5.8 against 6.0; 4 lanes: 6.3)
   //   above            one env per lane, with the targets prefetched into registers (PF) for the reference arm at every
   //                    size (7.1 against 7.8 us at 131 072 arms, 19.9 against 21.0 at 524 288, 39.4 against 39.5 at 1 M)
   //                    and for other arms up to 131 072 arms (long arms lose more to the lower occupancy than they gain)
   // MT_SPLIT = 0/2/4 and MT_PREFETCH = 0/1 override the choice for experiments and tests.
-  h->split = cfg->n_envs <= 32768 ? 4 : (cfg->n_envs <= 65536 ? 2 : 0);
+  h->split = cfg->n_envs <= 49152 ? 4 : (cfg->n_envs <= 65536 ? 2 : 0);
   h->prefetch = cfg->n_envs <= 131072;  // widened for the reference arm once the table is known (below)
   // The fused rollout keeps two lanes per env up to 131 072 arms (tools/fused_split_sweep.py, round 3: 3.60 against 4.50 us
   // per step at 98 304 arms, 4.37 against 4.50 at 131 072; one env per lane wins from 196 608 on).
