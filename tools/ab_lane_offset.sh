@@ -1,9 +1,10 @@
 #!/bin/bash
-# A/B of the row addressing on one box: the library as built against builds with -DMT_PLAIN_LANE_OFFSET=<mode>
-# (kernels.h, lane_offset): 1 = the offset as the optimiser leaves it (one v_lshl_add_u64 per access outside the entry
-# block), 2 = the renewal without `volatile`, 3 = renewal on loads only, 4 = on stores only.  us per step, the library's
-# own dispatch.   tools/ab_lane_offset.sh [name ...]   names = tools/_build/libmanytor_hip_<name>.so, built by hand with
-# those flags; default: plainoff
+# A/B of kernel builds on one box: the library as built against other builds of it, us per step by batch size
+# (tools/size_sweep.py: segment / steady incl. resets / fused), the library's own dispatch.
+#   tools/ab_lane_offset.sh [name ...]     names = tools/_build/libmanytor_hip_<name>.so, built by hand, e.g. with
+#   -DMT_PLAIN_LANE_OFFSET=1 (kernels.h, LaneOffset: no renewal of the lane offset anywhere) = "plainoff", the default.
+# (The loads-only / stores-only / non-volatile renewal variants of profiles/r03_ab_lane_offset_2_loads_stores.txt were
+# experiment builds of an earlier revision of kernels.h.)
 names=${*:-plainoff}
 for rep in 1 2; do
   for name in "" $names; do
