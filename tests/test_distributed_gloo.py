@@ -258,9 +258,10 @@ def test_bench_episode_loop_world2_gloo(steps, warmup):
     assert launches == max(L, 200) + warmup + 3 * steps and resets == gathers + 1
 
 
-def _measure_worker(rank, world, port, steps, warmup, q):
+def _measure_worker(rank, world, port, steps, warmup, phase, q):
     sys.path.insert(0, ROOT)
     import bench
+    bench.EpisodeLoop.phase = phase                       # what main() sets from --episode-phase (N > 1: half an episode)
     r, _, w = _init(rank, world, port)
     bar = D.make_host_barrier(r, w)
     fab = bench.Fabric(r, w, dist, torch, "cpu", bar, None)
@@ -277,19 +278,22 @@ def _measure_worker(rank, world, port, steps, warmup, q):
     dist.destroy_process_group()
 
 
-def test_bench_measure_protocol_world2_gloo():
+@pytest.mark.parametrize("phase", [0, 10])
+def test_bench_measure_protocol_world2_gloo(phase):
     """bench.measure + bench.Fabric -- the protocol every leg of an N > 1 invocation goes through (headline, the 1 M-arm
     strong leg, configs[3]) -- at world size 2 over gloo with the shared-memory barrier: every region launches exactly
     `steps` steps and contains a gather, the figures every leg reports are there, and both ranks agree on the number of
-    regions (rank 0's clock decides the time-based loops)."""
-    out = _spawn(_measure_worker, (20, 5))
+    regions (rank 0's clock decides the time-based loops).  phase = 10 is the N > 1 default: a region starts half-way
+    through an episode, so its one gather sits in the middle of it."""
+    out = _spawn(_measure_worker, (20, 5, phase))
     for key, (res, launches, gathers) in out.items():
         for k in ("elapsed", "ms_per_step", "ms_per_step_min", "ms_per_step_max", "step_us", "launches", "gather_us",
                   "gathers_per_region", "repeats", "prewarm", "episode_len", "value"):
             assert k in res, (key, k)
         assert res["episode_len"] == 20 and res["gathers_per_region"] == 1 and res["repeats"] >= 5
         assert res["launches"] == 20 * res["repeats"]
-        assert launches == res["prewarm"] + 5 + 20 * res["repeats"]
+        assert launches == res["prewarm"] + 5 + phase + 20 * res["repeats"]
         assert res["ms_per_step_min"] <= res["ms_per_step"] <= res["ms_per_step_max"]
-        # the loop is aligned after the warm-up, so a 20-step region is ONE step segment = one 0.05 ms lap
-        assert res["step_us"] == pytest.approx(50.0 / 20)
+        # aligned after the warm-up, a 20-step region is ONE step segment = one 0.05 ms lap; started half-way through an
+        # episode it is two segments around the episode end = two laps
+        assert res["step_us"] == pytest.approx((50.0 if phase == 0 else 100.0) / 20)
