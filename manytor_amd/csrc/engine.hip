@@ -104,6 +104,27 @@ int match_static(const DhConst& t, int dof) {
 
 // whole_rows: the launch covers the batch or a 256-aligned range of it (not the single-env view), so threads past the
 // end of the range may read on to the end of their block inside the rows (what the TT kernels do before their barrier)
+// Blocks per CU for a launch of the sampled-action prefetch kernel of a compile-time table (PF + TT, 74-76 VGPRs: six
+// blocks fit).  mt_rollout's two chains keep two such kernels on the chip at once; with six blocks per CU both are
+// resident in full up to ~400 k envs per chain and run their load and store phases in lock step.  Fewer resident blocks
+// make the chains take turns, and fewer rows are in flight per memory channel (tools/ab_blocks_per_cu.sh,
+// profiles/r03_variants.md section 12; us per step, no cap -> best cap):
+//   163 840 envs per chain 12.3 -> 11.6 (3 blocks)    196 608: 14.4 -> 13.3 (3)     262 144: 19.1 -> 18.0 (4)
+//   327 680: 22.9 -> 22.1 (4)     393 216: 27.4 -> 26.1 (4)     524 288: 35.2 -> 34.5 (5)     >= 786 432 and <= 131 072: nothing
+// Chain launches only (a whole-batch launch has the chip to itself).  The cap is applied at launch time the usual way,
+// with dynamic LDS nobody touches: a block then claims 1 / cap of the CU's 160 KB.  MT_BLOCKS_PER_CU overrides (0 = none).
+static int step_blocks_per_cu(mt_handle h, int64_t n_launch) {
+  if (h->blocks_per_cu_override >= 0) return h->blocks_per_cu_override;
+  if (n_launch >= h->n) return 0;
+  if (n_launch < 147456 || n_launch >= 655360) return 0;
+  return n_launch < 229376 ? 3 : (n_launch < 458752 ? 4 : 5);
+}
+static size_t lds_pad_for_blocks(int blocks_per_cu, size_t static_lds) {
+  if (blocks_per_cu <= 0) return 0;
+  const size_t per_block = (size_t)163840 / (size_t)blocks_per_cu - 1024;  // safely inside the bracket of that block count
+  return per_block > static_lds ? std::min<size_t>(per_block, 65536) - static_lds : 0;  // <= 64 KB in all: no attribute needed
+}
+
 template <class Tbl, bool LDS_OK>
 void launch_step_t(mt_handle h, const StepArgs& args, bool sample, bool whole_rows) {
   const dim3 g = grid_for(args.n), b(kBlock);
@@ -145,10 +166,12 @@ void launch_step_t(mt_handle h, const StepArgs& args, bool sample, bool whole_ro
   }
   if constexpr (ActionTrigTable<Tbl>::value) {
     if (tt) {
-      if (h->prefetch && args.n >= h->flat_from)  // HBM-bound launches: kernels.h, LaneOffset<false>
-        hipLaunchKernelGGL((step_kernel<Tbl, true, 0, false, kPrefetch, true, true>), g, b, 0, h->stream, args);
+      if (h->prefetch && args.n >= h->flat_from)  // HBM-bound launches: kernels.h, LaneOffset<false>; see step_blocks_per_cu
+        hipLaunchKernelGGL((step_kernel<Tbl, true, 0, false, kPrefetch, true, true>), g, b,
+                           lds_pad_for_blocks(step_blocks_per_cu(h, args.n), kTrigEntries * sizeof(SinCos)), h->stream, args);
       else if (h->prefetch)
-        hipLaunchKernelGGL((step_kernel<Tbl, true, 0, false, kPrefetch, true>), g, b, 0, h->stream, args);
+        hipLaunchKernelGGL((step_kernel<Tbl, true, 0, false, kPrefetch, true>), g, b,
+                           lds_pad_for_blocks(step_blocks_per_cu(h, args.n), kTrigEntries * sizeof(SinCos)), h->stream, args);
       else
         hipLaunchKernelGGL((step_kernel<Tbl, true, 0, false, 0, true>), g, b, 0, h->stream, args);
       return;
@@ -587,6 +610,7 @@ int mt_create(mt_handle* out, const mt_config* cfg) {
   if (cfg->n_envs < 2 * 256) h->chains = 1;
   if (const char* env = std::getenv("MT_LAZY_CHAINS")) h->lazy_chains = std::atoi(env) != 0;  // 0: join at the end of every call
   if (const char* env = std::getenv("MT_FLAT_FROM")) h->flat_from = std::max<long long>(0, std::atoll(env));
+  if (const char* env = std::getenv("MT_BLOCKS_PER_CU")) h->blocks_per_cu_override = std::max(0, std::min(8, std::atoi(env)));
   h->prefetch_forced = false;
   if (const char* env = std::getenv("MT_PREFETCH")) {
     h->prefetch = std::atoi(env) != 0;
