@@ -779,7 +779,10 @@ const char* mt_step_kernel_name(mt_handle h) {
     h->kernel_name += " [mt_rollout: " + std::to_string(h->chains) + " chains of " + std::to_string(chain_span(h, h->chains)) +
                       " envs, " + (h->trig == 0 && !h->lds_table && h->chain_split ? "L=" + std::to_string(h->chain_split)
                                    : std::string(h->trig == 0 && !h->lds_table && h->chain_prefetch
-                                                     ? (chain_span(h, h->chains) >= h->flat_from ? "pf=8, flat=1" : "pf=8") : "pf=0")) + "]";
+                                                     ? (chain_span(h, h->chains) >= h->flat_from ? "pf=8, flat=1" : "pf=8") : "pf=0")) +
+                      ((h->trig == 0 && !h->lds_table && !h->chain_split && h->chain_prefetch && h->trig_steps &&
+                        step_blocks_per_cu(h, chain_span(h, h->chains)) > 0)
+                           ? ", " + std::to_string(step_blocks_per_cu(h, chain_span(h, h->chains))) + " blocks/CU" : std::string()) + "]";
   return h->kernel_name.c_str();
 }
 
