@@ -104,15 +104,16 @@ int match_static(const DhConst& t, int dof) {
 
 // whole_rows: the launch covers the batch or a 256-aligned range of it (not the single-env view), so threads past the
 // end of the range may read on to the end of their block inside the rows (what the TT kernels do before their barrier)
-// Blocks per CU for a launch of the sampled-action prefetch kernel of a compile-time table (PF + TT, 74-76 VGPRs: six
-// blocks fit).  mt_rollout's two chains keep two such kernels on the chip at once; with six blocks per CU both are
-// resident in full up to ~400 k envs per chain and run their load and store phases in lock step.  Fewer resident blocks
-// make the chains take turns, and fewer rows are in flight per memory channel (tools/ab_blocks_per_cu.sh,
-// profiles/r03_variants.md section 12; us per step, no cap -> best cap):
-//   163 840 envs per chain 12.3 -> 11.6 (3 blocks)    196 608: 14.4 -> 13.3 (3)     262 144: 19.1 -> 18.0 (4)
-//   327 680: 22.9 -> 22.1 (4)     393 216: 27.4 -> 26.1 (4)     524 288: 35.2 -> 34.5 (5)     >= 786 432 and <= 131 072: nothing
-// Chain launches only (a whole-batch launch has the chip to itself).  The cap is applied at launch time the usual way,
-// with dynamic LDS nobody touches: a block then claims 1 / cap of the CU's 160 KB.  MT_BLOCKS_PER_CU overrides (0 = none).
+// Blocks per CU for a chain launch of the sampled-action prefetch kernel of a compile-time table (PF + TT, 74-76 VGPRs: six
+// blocks fit).  Between ~300 k and ~1.3 M arms in the batch the chains run faster with fewer resident blocks than the
+// registers allow -- fewer rows in flight per memory channel, and the chains' kernels take turns instead of running their
+// load and store phases side by side.  The best cap follows the TOTAL batch, whatever the number of chains
+// (tools/ab_blocks_per_cu.sh, profiles/r03_variants.md section 12; us per step, no cap -> best cap):
+//   327 680 arms 12.3 -> 11.6 (3 blocks)    393 216: 14.4 -> 13.3 (3)     524 288: 19.1 -> 18.0 (4)     655 360: 22.9 -> 22.1 (4)
+//   786 432: 27.4 -> 26.1 (4)     1 048 576: 35.2 -> 34.5 (5)     >= 1 310 720 and <= 262 144: nothing
+// Keyed here by the envs of the launch with the default two chains in mind (half the batch).  Chain launches only.  The
+// cap is applied at launch time the usual way, with dynamic LDS nobody touches: a block then claims 1 / cap of the CU's
+// 160 KB.  MT_BLOCKS_PER_CU overrides (0 = none).
 static int step_blocks_per_cu(mt_handle h, int64_t n_launch) {
   if (h->blocks_per_cu_override >= 0) return h->blocks_per_cu_override;
   if (n_launch >= h->n) return 0;
