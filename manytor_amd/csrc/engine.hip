@@ -110,14 +110,14 @@ int match_static(const DhConst& t, int dof) {
 // load and store phases side by side.  The best cap follows the TOTAL batch, whatever the number of chains
 // (tools/ab_blocks_per_cu.sh, profiles/r03_variants.md section 12; us per step, no cap -> best cap):
 //   327 680 arms 12.3 -> 11.6 (3 blocks)    393 216: 14.4 -> 13.3 (3)     524 288: 19.1 -> 18.0 (4)     655 360: 22.9 -> 22.1 (4)
-//   786 432: 27.4 -> 26.1 (4)     1 048 576: 35.2 -> 34.5 (5)     >= 1 310 720 and <= 262 144: nothing
+//   786 432: 27.4 -> 26.1 (4)     1 048 576: 35.2 -> 34.5 (5)     >= 1 179 648 and <= 262 144: nothing
 // Keyed here by the envs of the launch with the default two chains in mind (half the batch).  Chain launches only.  The
 // cap is applied at launch time the usual way, with dynamic LDS nobody touches: a block then claims 1 / cap of the CU's
 // 160 KB.  MT_BLOCKS_PER_CU overrides (0 = none).
 static int step_blocks_per_cu(mt_handle h, int64_t n_launch) {
   if (h->blocks_per_cu_override >= 0) return h->blocks_per_cu_override;
   if (n_launch >= h->n) return 0;
-  if (n_launch < 147456 || n_launch >= 655360) return 0;
+  if (n_launch < 147456 || n_launch >= 589824) return 0;  // (1 179 648 arms: a tie; 294 912: -2 % with 3: r03_ab_blocks_edges.txt)
   return n_launch < 229376 ? 3 : (n_launch < 458752 ? 4 : 5);
 }
 static size_t lds_pad_for_blocks(int blocks_per_cu, size_t static_lds) {
