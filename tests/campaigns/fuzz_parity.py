@@ -64,6 +64,9 @@ while time.time() < deadline:
     cases += 1
     if time.time() - last_note > 45:                 # a long silent run looks hung to the GPU box's watchdog
         print(f"... {cases} configurations so far", flush=True)
+        if os.path.isdir(os.path.join(ROOT, "gpurun_out")):   # a sign of life that survives a `| tail` behind this script
+            with open(os.path.join(ROOT, "gpurun_out", ".campaign_progress"), "a") as pf:
+                pf.write(f"{os.path.basename(__file__)} {cases}\n")
         last_note = time.time()
     guarded += ls.guarded
     compared += ls.compared
