@@ -749,6 +749,7 @@ def main():
         out["secondary"]["other_configs"] = {}
         for label, n2, tbl, rad in (("configs[1]: 65536 arms, 4-DoF", 65536, m.REF_DH_TABLE, 51.3),
                                     ("131072 arms, 4-DoF (1 M arms over 8 GPUs, per-GPU shard)", 131072, m.REF_DH_TABLE, 51.3),
+                                    ("524288 arms, 4-DoF (configs[3] over 8 GPUs, per-GPU shard)", 524288, m.REF_DH_TABLE, 51.3),
                                     ("4194304 arms, 4-DoF (1 GB working set: pure HBM regime)", 4194304, m.REF_DH_TABLE, 51.3),
                                     ("configs[4]: 1048576 arms, 7-DoF table", 1048576, m.DH7_TABLE, 92.6)):
             us, kname = time_step_launches(m, n2, tbl, rad, args.targets, dev, args.seed,

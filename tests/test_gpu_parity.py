@@ -1150,6 +1150,39 @@ def test_rollout_in_independent_chains_equals_plain_launches(m, monkeypatch, n, 
         np.testing.assert_array_equal(e.get(getattr(m.lib, f)), ref.get(getattr(m.lib, f)), err_msg=f)
 
 
+@pytest.mark.parametrize("cap", [1, 3, 5, 8])
+def test_occupancy_cap_of_the_chain_launches_changes_nothing_but_the_launch(m, monkeypatch, cap):
+    """The chain launches of the sampled-action prefetch kernel may be capped to fewer resident blocks per CU with dynamic
+    LDS nobody touches (engine.hip: step_blocks_per_cu; MT_BLOCKS_PER_CU overrides the size-based choice).  Every cap
+    must launch (the pad stays within the 64 KB a launch may ask for without an attribute) and give the bits of the
+    uncapped engine -- at a size where the default applies a cap (400 003 arms: three blocks) and for both addressing
+    forms of the kernel."""
+    fields = STATE_FIELDS + STEP_FIELDS
+    n, k = 400003, 7
+    got = {}
+    for setting in ("0", str(cap), None):
+        for flat_from in ("0", str(1 << 40)):
+            if setting is None:
+                monkeypatch.delenv("MT_BLOCKS_PER_CU", raising=False)
+            else:
+                monkeypatch.setenv("MT_BLOCKS_PER_CU", setting)
+            monkeypatch.setenv("MT_FLAT_FROM", flat_from)
+            e = m.StepEngine(n, k, pickup_tol=20.0)
+            name = e.step_kernel_name()
+            assert "2 chains" in name and "pf=8" in name, name
+            assert ("blocks/CU" in name) == (setting != "0"), name
+            e.reset_random(21, 0)
+            e.rollout(6, 21, 0)
+            e.reset_random(21, 1)
+            e.rollout(5, 21, 0)
+            got[(setting, flat_from)] = {f: e.get(getattr(m.lib, f)) for f in fields}
+            e.close()
+    ref = got[("0", "0")]
+    for key, vals in got.items():
+        for f in fields:
+            np.testing.assert_array_equal(vals[f], ref[f], err_msg=f"{key}: {f}")
+
+
 @pytest.mark.parametrize("sampled", [True, False])
 @pytest.mark.parametrize("n,k,table_name", [(100003, 7, "ref"), (262144, 3, "ref"), (70001, 7, "dh7"), (999, 9, "ref")])
 def test_flat_row_addressing_equals_renewed_lane_offsets(m, monkeypatch, n, k, table_name, sampled):
