@@ -610,8 +610,9 @@ int mt_create(mt_handle* out, const mt_config* cfg) {
   if (const char* env = std::getenv("MT_CHAINS")) h->chains = std::max(1, std::min((int)mt_engine::kMaxChains, std::atoi(env)));
   if (cfg->n_envs < 2 * 256) h->chains = 1;
   if (const char* env = std::getenv("MT_LAZY_CHAINS")) h->lazy_chains = std::atoi(env) != 0;  // 0: join at the end of every call
-  if (const char* env = std::getenv("MT_FLAT_FROM")) h->flat_from = std::max<long long>(0, std::atoll(env));
-  if (const char* env = std::getenv("MT_BLOCKS_PER_CU")) h->blocks_per_cu_override = std::max(0, std::min(8, std::atoi(env)));
+  if (const char* env = std::getenv("MT_FLAT_FROM"); env && *env) h->flat_from = std::max<long long>(0, std::atoll(env));
+  if (const char* env = std::getenv("MT_BLOCKS_PER_CU"); env && *env)  // (set but empty = not set: atoi("") would mean "no cap")
+    h->blocks_per_cu_override = std::max(0, std::min(8, std::atoi(env)));
   h->prefetch_forced = false;
   if (const char* env = std::getenv("MT_PREFETCH")) {
     h->prefetch = std::atoi(env) != 0;
