@@ -432,6 +432,15 @@ __device__ __forceinline__ float4 trig_table_load(const float* table) {
   return v;
 }
 // every wave of the block executes this exactly once (the barrier counts arrivals, wherever the s_barrier sits)
+// Values that must be COMPLETE, in the instruction stream too, before the next barrier / wait: the compiler is free to sink
+// pure arithmetic below a __syncthreads(), and it does so with the whole Philox block of the step kernels -- which then runs
+// AFTER the wait for the table load, i.e. after (nearly) every load of the kernel had come back (vmcnt counts in issue
+// order, and the conditional prefetch loads make the count conservative), instead of under their latency.
+template <int D>
+__device__ __forceinline__ void complete_before_here(float (&v)[D]) {
+#pragma unroll
+  for (int j = 0; j < D; ++j) asm volatile("" : "+v"(v[j]));
+}
 __device__ __forceinline__ void trig_table_commit(SinCos* lds, const float4& v) {
   if (threadIdx.x < kTrigVec4) reinterpret_cast<float4*>(lds)[threadIdx.x] = v;
   __syncthreads();
@@ -746,6 +755,10 @@ __global__ __launch_bounds__(kBlock, (PF ? 1 : step_min_waves<Tbl, TRIG>())) voi
 #pragma unroll
     for (int k = 0; k < PF; ++k)
       if (k < a.K) {
+        // (Loads under a condition make every later s_waitcnt vmcnt(N) conservative -- the compiler can only count the loads
+        // certainly issued behind the one it waits for -- so the kinematics starts once nearly all prefetched rows are back.
+        // Unconditional loads, the last row again for the slots past K, give exact counts and were measured: +2 % at
+        // 98 304-131 072 envs, nothing elsewhere: profiles/r03_ab_unconditional_prefetch.txt.)
         const float* row = a.points + (int64_t)(3 * k) * ld;
 #pragma unroll
         for (int q = 0; q < 3; ++q) tx[k][q] = ldr(row + q * ld, o4);
@@ -777,7 +790,9 @@ __global__ __launch_bounds__(kBlock, (PF ? 1 : step_min_waves<Tbl, TRIG>())) voi
   }
   MT_STAMP(a, i, 1);  // action known (Philox done / staged action loaded)
   if (TT) {
-    trig_table_commit(trig_lds, trig_v);  // the table load has had the pose loads and the Philox block to arrive
+    // (complete_before_here(act) -- the Philox block ahead of this wait -- was measured here: nothing at >= 262 144 envs,
+    // +1 % at 131 072; the lane-split kernels gain 1-2 % and have it: profiles/r03_ab_philox_before_wait.txt)
+    trig_table_commit(trig_lds, trig_v);  // the table load has had the pose loads to arrive
     if (i >= a.n) return;
   }
   if (kLean) {  // goals = action (manytor.py:184): the old pose is in registers already
@@ -992,7 +1007,10 @@ __global__ __launch_bounds__(kBlock) void step_split_kernel(const StepArgs a) {
     }
   }
 
-  if (TT) trig_table_commit(trig_lds, trig_v);
+  if (TT) {
+    complete_before_here(act);  // Philox under the loads' latency: 32 768 arms 4.76 -> 4.68 us per step, 65 536: 5.84 -> 5.77
+    trig_table_commit(trig_lds, trig_v);
+  }
 
   // ---- kinematics: the poses of route_kinematics, one half per sub-lane parity ------------------------------
   float el[3], e[3];
