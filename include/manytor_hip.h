@@ -137,10 +137,7 @@ MT_API const char* mt_status_string(int status);
 MT_API const char* mt_last_error(mt_handle h);
 MT_API int mt_device_count(int* count);
 
-/* Environment()/Multienv() constructors, manytor.py:130-139 / :77-82.  All state lives in ONE device allocation made here.
- * For batches of more than 3 M arms that allocation is placed by trial (allocated, probed with the step's store pattern,
- * freed and allocated again while the physical placement is a slow one: up to eight allocations, a few ms in all;
- * MT_PLACEMENT_PROBE=0 in the environment turns that off). */
+/* Environment()/Multienv() constructors, manytor.py:130-139 / :77-82. */
 MT_API int mt_create(mt_handle* out, const mt_config* cfg);
 MT_API int mt_destroy(mt_handle h);
 /* Which instantiation mt_step / mt_step_random launch for this handle (the schedule is picked by batch size and table

@@ -656,62 +656,13 @@ int mt_create(mt_handle* out, const mt_config* cfg) {
                o_trace = take((cfg->flags & MT_FLAG_TRACE) ? (size_t)cfg->substeps * 3 * ld * 4 : 0),
                o_zmin = take((cfg->flags & MT_FLAG_DEBUG_ZMIN) ? ld * 4 : 0), o_trig = take(kTrigEntries * sizeof(SinCos));
   h->arena_bytes = off;
-  // Very large batches (one launch per step: > 3 M arms): which PHYSICAL frames the arena lands on changes the step time by
-  // ~10 % (4 194 304 arms: 170-177 against 190-197 us per step); the placement changes from one allocate / free cycle to the
-  // next at the SAME virtual address, and the step's many-row STORE pattern sees it (placement_probe_kernel: 7.9 against
-  // 6.9 TB/s; profiles/r03_variants.md sections 5 and 14).  So such an arena is placed by trial: allocate, time the probe,
-  // and if it runs below the bar free the arena and allocate again -- up to eight times (under a ms each, once per
-  // handle; the last placement is kept whatever it is).  MT_PLACEMENT_PROBE=0 turns it off, =2 reports the probes on stderr.
-  constexpr double kPlacementGoodGBs = 7400.0;
-  StepArgs& a = h->args;
-  a.n = h->n;
-  a.ld = h->ld;
-  a.K = h->K;
-  bool place_by_trial = h->n > 3145728 && h->D <= 8 && h->K <= 8;
-  if (const char* env = std::getenv("MT_PLACEMENT_PROBE"); env && *env) place_by_trial = place_by_trial && std::atoi(env) != 0;
-  const double probe_bytes = (double)h->n * (4.0 * (h->D + 3 * h->K + 3 + 2) + 4.0 + 1.0);
-  double best_gbs = 0.0;
-  for (int attempt = 0;; ++attempt) {
-    if (hipMalloc(&h->arena, h->arena_bytes) != hipSuccess) {
-      (void)hipGetLastError();
-      h->arena = nullptr;
-      return bail(MT_ERR_ALLOC, "hipMalloc of the state arena failed (" + std::to_string(h->arena_bytes) + " bytes)");
-    }
-    MT_HIP_C(hipMemsetAsync(h->arena, 0, h->arena_bytes, h->stream));
-    if (!place_by_trial) break;
-    char* pb = (char*)h->arena;
-    a.goals = (float*)(pb + o_goal);
-    a.obs = (float*)(pb + o_obs);
-    a.alive = (uint32_t*)(pb + o_alive);
-    a.total_reward = (float*)(pb + o_tot);
-    a.reward = (int32_t*)(pb + o_rew);
-    a.done = (uint8_t*)(pb + o_done);
-    a.ee = (float*)(pb + o_ee);
-    float ms = 0.f;
-    for (int rep = 0; rep < 5; ++rep) {  // one untimed launch, four timed
-      if (rep == 1) MT_HIP_C(hipEventRecord(h->ev0, h->stream));
-      hipLaunchKernelGGL(placement_probe_kernel, grid_for(h->n), dim3(kBlock), 0, h->stream, a, h->D);
-    }
-    MT_HIP_C(hipGetLastError());
-    MT_HIP_C(hipEventRecord(h->ev1, h->stream));
-    MT_HIP_C(hipEventSynchronize(h->ev1));
-    MT_HIP_C(hipEventElapsedTime(&ms, h->ev0, h->ev1));
-    const double gbs = probe_bytes / (ms / 4.0 * 1e-3) / 1e9;
-    h->placement_probe_gbs.push_back((float)gbs);
-    best_gbs = std::max(best_gbs, gbs);
-    // the bar: the figure that separated the modes where this was measured; on a box whose placements all stay below it,
-    // from the fourth attempt on, whatever comes within half a percent of the best placement seen
-    const double bar = attempt < 3 ? kPlacementGoodGBs : std::min(kPlacementGoodGBs, best_gbs * 0.995);
-    if (gbs >= bar || attempt == 7) break;
-    MT_HIP_C(hipFree(h->arena));
-    h->arena = nullptr;
+  if (hipMalloc(&h->arena, h->arena_bytes) != hipSuccess) {
+    (void)hipGetLastError();
+    return bail(MT_ERR_ALLOC, "hipMalloc of the state arena failed (" + std::to_string(h->arena_bytes) + " bytes)");
   }
-  if (place_by_trial && std::getenv("MT_PLACEMENT_PROBE") && std::atoi(std::getenv("MT_PLACEMENT_PROBE")) == 2) {
-    std::string line = "[manytor] arena placement probes (GB/s of the store pattern, the last one kept):";
-    for (float v : h->placement_probe_gbs) line += " " + std::to_string((int)v);
-    std::fprintf(stderr, "%s\n", line.c_str());
-  }
+  MT_HIP_C(hipMemsetAsync(h->arena, 0, h->arena_bytes, h->stream));
   char* base = (char*)h->arena;
+  StepArgs& a = h->args;
   a.actions = (float*)(base + o_act);
   a.goals = (float*)(base + o_goal);
   a.points = (float*)(base + o_pts);

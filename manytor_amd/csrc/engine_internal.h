@@ -42,7 +42,6 @@ struct mt_engine {
   bool custom_frames = false;  // obs_frame / ee_frame are not the reference's last two rows: RtTableF kernels
   int split = 0;          // step_split_kernel<..., L>: one env over L = 2 or 4 lanes (0 = one env per lane)
   int rollout_split = 0;  // the same choice for rollout_split_kernel (it pays up to larger batches: mt_create)
-  std::vector<float> placement_probe_gbs;  // mt_create, very large batches: store-pattern GB/s of every arena placement tried (the last one was kept)
   int blocks_per_cu_override = -1;  // MT_BLOCKS_PER_CU: occupancy cap of the PF + TT step launches (engine.hip: step_blocks_per_cu)
   int64_t flat_from = 393216;  // launches of the prefetch kernel over at least this many envs take its FLAT form (kernels.h,
                                // LaneOffset<false>: the HBM-bound regime); MT_FLAT_FROM overrides

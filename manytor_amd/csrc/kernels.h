@@ -317,29 +317,6 @@ __device__ __forceinline__ uint32_t step_index(const StepArgs& a) {
   return a.major_base ? a.major + *a.major_base : a.major;
 }
 
-// The STORES of one step without anything else, zeros onto a zero-filled arena: the rows a step writes, with the step's own
-// store kinds.  mt_create times it on a freshly allocated arena of a very large batch (engine.hip, placement by trial): this
-// many-row store pattern sees the slow physical placements of profiles/r03_variants.md section 5 / 14 (7.9 against 6.9 TB/s
-// at 4 194 304 arms) -- a plain copy between two rows does not, and neither does the same pattern with the step's loads
-// in front of it.  D <= 8, K <= 8.
-__global__ __launch_bounds__(kBlock) void placement_probe_kernel(const StepArgs a, int D) {
-  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-  if (i >= a.n) return;
-  const int64_t ld = a.ld;
-#pragma unroll
-  for (int j = 0; j < 8; ++j)
-    if (j < D) (a.goals + j * ld)[i] = 0.f;
-#pragma unroll
-  for (int r = 0; r < 24; ++r)
-    if (r < 3 * a.K) __builtin_nontemporal_store(0.f, a.obs + r * ld + i);
-#pragma unroll
-  for (int q = 0; q < 3; ++q) __builtin_nontemporal_store(0.f, a.ee + q * ld + i);
-  a.alive[i] = 0u;
-  a.total_reward[i] = 0.f;
-  __builtin_nontemporal_store((int32_t)0, a.reward + i);
-  __builtin_nontemporal_store((uint8_t)0, a.done + i);
-}
-
 // Environment.action_sample for one env (manytor.py:215-217): D integer degrees from one Philox block.
 template <int D>
 __device__ __forceinline__ void draw_action(uint64_t seed, uint64_t env_id, uint32_t step_idx, float (&act)[D]) {

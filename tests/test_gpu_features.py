@@ -516,28 +516,3 @@ def test_snapshot_gather_taken_per_chain_while_forked(m, monkeypatch):
         for x, y in zip(out[chains], out["1"]):
             np.testing.assert_array_equal(x, y)
     assert np.abs(out["1"][0]).max() > 0 and np.abs(out["1"][1]).max() > 0 and not out["1"][2].any()
-
-
-def test_arena_placed_by_trial_is_the_same_engine(m, monkeypatch):
-    """mt_create places the arena of a very large batch (> 3 M arms) by trial: allocate, time the step's store pattern on
-    it, free and allocate again while the placement is a slow one (engine.hip; MT_PLACEMENT_PROBE=0 turns it off).  The
-    probe writes zeros onto the zero-filled arena, so nothing but the physical frames differs: same bits as an engine
-    created without it, and creation stays cheap."""
-    import time
-    n, k = 3200003, 2
-    out = {}
-    for setting in ("0", "1"):
-        monkeypatch.setenv("MT_PLACEMENT_PROBE", setting)
-        t0 = time.perf_counter()
-        e = m.StepEngine(n, k, pickup_tol=20.0)
-        e.sync()
-        assert time.perf_counter() - t0 < 5.0
-        e.reset_random(4, 0)
-        e.rollout(4, 4, 0)
-        e.reset_done(4)
-        e.rollout(3, 4, 4)
-        out[setting] = {f: e.get(getattr(m.lib, f)) for f in ("F_GOALS", "F_POINTS", "F_ALIVE", "F_TOTAL_REWARD", "F_OBS",
-                                                             "F_REWARD", "F_DONE", "F_EE", "F_DONE_BITS", "F_EPISODES")}
-        e.close()
-    for f, v in out["0"].items():
-        np.testing.assert_array_equal(out["1"][f], v, err_msg=f)
