@@ -137,10 +137,7 @@ MT_API const char* mt_status_string(int status);
 MT_API const char* mt_last_error(mt_handle h);
 MT_API int mt_device_count(int* count);
 
-/* Environment()/Multienv() constructors, manytor.py:130-139 / :77-82.  All state lives in ONE device allocation made here.
- * For the reference arm with more than 3 M arms the handle is placed by trial: six real steps are timed on it and, while
- * they run in the slow placement mode of such arenas, it is created again with the slow memory held (at most five
- * handles, ~2 ms each); what is returned is in the freshly-created state either way.  MT_PLACEMENT_PROBE=0 turns it off. */
+/* Environment()/Multienv() constructors, manytor.py:130-139 / :77-82. */
 MT_API int mt_create(mt_handle* out, const mt_config* cfg);
 MT_API int mt_destroy(mt_handle h);
 /* Which instantiation mt_step / mt_step_random launch for this handle (the schedule is picked by batch size and table

@@ -524,7 +524,7 @@ int mt_device_count(int* count) {
   return MT_OK;
 }
 
-static int create_once(mt_handle* out, const mt_config* cfg) {
+int mt_create(mt_handle* out, const mt_config* cfg) {
   MT_REQUIRE(nullptr, out != nullptr && cfg != nullptr, "out/cfg is NULL");
   *out = nullptr;
   MT_REQUIRE(nullptr, cfg->struct_size == (int32_t)sizeof(mt_config), "mt_config.struct_size mismatch");
@@ -735,92 +735,6 @@ static int create_once(mt_handle* out, const mt_config* cfg) {
 #undef MT_HIP_C
   *out = h;
   return MT_OK;
-}
-
-// Batches that run as ONE launch per step (> 3 M arms) of the reference arm: which PHYSICAL frames the arena lands on
-// decides between two well separated step times (4 194 304 arms: 170-177 us or 190-197 us, nothing in between, on every box
-// of rounds 2 and 3), the placement changes with every allocate / free cycle at the same virtual address, and only the
-// step itself tells the modes apart -- copies, load + store streams and a store-pattern probe do not, or not reliably
-// (profiles/r03_variants.md sections 5 and 14).  So the handle is created, a few REAL steps are timed on it, and if they
-// run below 5.35 TB/s of the bytes a sampled step moves (the slow mode is 5.0-5.15, the fast one 5.5-5.75) it is destroyed
-// and created again, at most four times more; the one that is kept is put back into the state mt_create leaves (arena
-// zeroed, table refilled, not reset).  ~2 ms per attempt, once per handle.  MT_PLACEMENT_PROBE=0 turns it off, =2 reports.
-static int time_real_steps(mt_handle h, float* us_per_step) {
-  int rc = mt_reset_random(h, 0, 0);
-  if (rc == MT_OK) rc = mt_rollout(h, 2, 0, 0);
-  if (rc != MT_OK) return rc;
-  MT_HIP(h, hipEventRecord(h->ev0, h->stream));
-  rc = mt_rollout(h, 6, 0, 2);
-  if (rc != MT_OK) return rc;
-  MT_HIP(h, hipEventRecord(h->ev1, h->stream));
-  MT_HIP(h, hipEventSynchronize(h->ev1));
-  float ms = 0.f;
-  MT_HIP(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
-  *us_per_step = ms * 1e3f / 6.f;
-  return MT_OK;
-}
-static int restore_created_state(mt_handle h) {
-  int rc = join_chains(h);
-  if (rc) return rc;
-  MT_HIP(h, hipMemsetAsync(h->arena, 0, h->arena_bytes, h->stream));
-  hipLaunchKernelGGL(fill_trig_table_kernel, dim3(1), dim3(kBlock), 0, h->stream, const_cast<float*>(h->args.trig_table));
-  rc = check_launch(h, "fill_trig_table_kernel");
-  if (rc) return rc;
-  h->args.flags = h->cfg.flags & ~kFlagWholeGoals;
-  h->args.major = 0;
-  h->args.episode0 = 0;
-  h->args.seed_lo = h->args.seed_hi = 0;
-  h->graph_seen.clear();
-  h->is_reset = false;
-  MT_HIP(h, hipStreamSynchronize(h->stream));
-  return MT_OK;
-}
-
-int mt_create(mt_handle* out, const mt_config* cfg) {
-  int rc = create_once(out, cfg);
-  if (rc != MT_OK) return rc;
-  mt_handle h = *out;
-  int mode = 1;
-  if (const char* env = std::getenv("MT_PLACEMENT_PROBE"); env && *env) mode = std::atoi(env);
-  if (mode == 0 || h->n <= 3145728 || h->chains != 1 || h->static_kind != 1 || h->trace || (h->cfg.flags & MT_FLAG_DEBUG_ZMIN)) return MT_OK;
-  const double good_us = (double)h->n * (8.0 * h->D + 24.0 * h->K + 33.0) / 5.35e12 * 1e6;
-  std::string report = "[manytor] placement by trial, us per step (good: <= " + std::to_string((int)good_us) + "):";
-  std::vector<void*> held;
-  for (int attempt = 0;; ++attempt) {
-    float us = 0.f;
-    rc = time_real_steps(h, &us);
-    if (rc != MT_OK) break;
-    report += " " + std::to_string(us);
-    if (us <= good_us || attempt == 4) {
-      rc = restore_created_state(h);
-      break;
-    }
-    // A plain destroy / create cycle gets the same frames back (measured: five slow attempts in a row): the slow frames are
-    // kept occupied by a block of the arena's size while the next handle is created, and released at the end.
-    const size_t bytes = h->arena_bytes;
-    const int device = h->cfg.device;
-    (void)mt_destroy(h);
-    *out = nullptr;
-    {
-      DeviceGuard guard(device);
-      void* hold = nullptr;
-      if (hipMalloc(&hold, bytes) == hipSuccess) held.push_back(hold); else (void)hipGetLastError();
-    }
-    rc = create_once(out, cfg);
-    if (rc != MT_OK) break;
-    h = *out;
-  }
-  {
-    DeviceGuard guard(cfg->device);
-    for (void* p : held) (void)hipFree(p);
-  }
-  if (rc != MT_OK && *out == nullptr) return rc;
-  if (mode == 2) std::fprintf(stderr, "%s\n", report.c_str());
-  if (rc != MT_OK) {
-    (void)mt_destroy(h);
-    *out = nullptr;
-  }
-  return rc;
 }
 
 int mt_destroy(mt_handle h) {

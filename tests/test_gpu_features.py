@@ -516,35 +516,3 @@ def test_snapshot_gather_taken_per_chain_while_forked(m, monkeypatch):
         for x, y in zip(out[chains], out["1"]):
             np.testing.assert_array_equal(x, y)
     assert np.abs(out["1"][0]).max() > 0 and np.abs(out["1"][1]).max() > 0 and not out["1"][2].any()
-
-
-def test_engine_placed_by_trial_is_the_engine_mt_create_always_made(m, monkeypatch):
-    """mt_create places a very large batch of the reference arm (> 3 M arms: one launch per step) by trial: a few REAL steps
-    are timed on the new handle, and while they run in the slow mode the handle is destroyed and created again with the
-    slow frames kept occupied (engine.hip; MT_PLACEMENT_PROBE=0 turns it off).  The handle that is kept must be in exactly
-    the state mt_create leaves: every field zero, not reset (stepping is refused), and from there the same bits as a
-    handle created without the trial."""
-    import time
-    n, k = 3200003, 7
-    out = {}
-    fields = ("F_GOALS", "F_POINTS", "F_ALIVE", "F_TOTAL_REWARD", "F_OBS", "F_REWARD", "F_DONE", "F_EE", "F_DONE_BITS", "F_EPISODES",
-              "F_LAST_RETURN", "F_RETURN_RING")
-    for setting in ("0", "1"):
-        monkeypatch.setenv("MT_PLACEMENT_PROBE", setting)
-        t0 = time.perf_counter()
-        e = m.StepEngine(n, k, pickup_tol=20.0)
-        e.sync()
-        assert time.perf_counter() - t0 < 10.0
-        for f in fields:
-            assert not e.get(getattr(m.lib, f)).any(), f"{f} is not zero after mt_create (MT_PLACEMENT_PROBE={setting})"
-        assert e.bad_action_count() == 0
-        with pytest.raises(RuntimeError):
-            e.rollout(1, 4, 0)                     # not reset yet
-        e.reset_random(4, 0)
-        e.rollout(4, 4, 0)
-        e.reset_done(4)
-        e.rollout(3, 4, 4)
-        out[setting] = {f: e.get(getattr(m.lib, f)) for f in fields}
-        e.close()
-    for f, v in out["0"].items():
-        np.testing.assert_array_equal(out["1"][f], v, err_msg=f)
