@@ -2,8 +2,9 @@
 """Benchmark of the hot path: env-steps/sec of the batched manipulator step on MI355X.
 
     python bench.py                                   # 1 GPU, 1 048 576 arms, 4-DoF, K=7
+    python bench.py --gpus N --steps K --warmup W     # N GPUs of one node: the script starts its own N ranks
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-           --master-port P bench.py --gpus N --steps K --warmup W
+           --master-port P bench.py --gpus N --steps K --warmup W          # ... or runs as the ranks torchrun started
 
 One "step" = one Environment.step() (manytor.py:255-260: 25 interpolated sub-steps of DH forward
 kinematics, ground flag, observation, pickup, reward, return) for EVERY env of the batch, with the
@@ -12,17 +13,27 @@ resident in HBM when the timed region starts.  Every `episode_len` steps the ret
 over the ranks (mt_gather_returns: RCCL all-gather straight from the arena, the only collective) and
 all envs are reset (test_multi.py:32-34).
 
+Launching (`self_launch`): with --gpus N > 1 and no WORLD_SIZE in the environment the process is only a launcher -- before
+anything touches torch or HIP it starts N fresh children of this script (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR =
+127.0.0.1 / a free MASTER_PORT), relays rank 0's one JSON line to its own stdout and everything else to stderr, returns the
+worst exit code, and ends the whole group on the first failure or on --launch-timeout.  Under torchrun (WORLD_SIZE set)
+nothing of that runs.
+
+What N > 1 measures: the metric is "env-steps/sec (whole node), 1M parallel 4-DoF arms", so the headline of an N > 1 line is
+that workload -- 1 048 576 arms SHARDED over the N GPUs ("scaling": "strong") -- and `secondary` holds the weak-scaling leg
+(1 048 576 arms per GPU) and BASELINE.json configs[3] (4 194 304 arms sharded), each per-step and fused.  At N = 1 strong and
+weak are the same job.  --envs-per-gpu / --envs-total pick another headline.
+
 Timing protocol (robust to short --steps; `measure()`): a time-based pre-warm brings the GPU to its steady clock, then W
 untimed warm-up steps, the running episode is ended so that a region starts an episode (N = 1) or half-way through one (N > 1:
 the region's RCCL exchange then runs beside the steps behind the episode end; --episode-phase), then the region of EXACTLY K
 steps -- bracketed by barrier + torch.cuda.synchronize() on both sides, max over ranks -- is run `repeats` times; `ms_per_step` /
-`value` come from the MEDIAN region (min / max beside it).  The device time of a step is measured with HIP events on the
-engine's stream around the step launches of every region (mt_rollout may run a step as two concurrent launches on two
-streams, forked from and joined to that stream inside the laps; `roofline` says so).
-
-With N > 1 the same invocation then measures, on the same ranks, the two strong-scaling configurations BASELINE.json's
-north_star names -- `secondary.strong_1m` (1 048 576 arms sharded) and `secondary.config3` (4 194 304 arms sharded), each as
-per-step launches and as fused segments -- so that the driver's one command per N captures them.
+`value` come from the MEDIAN region (min / max beside it).  Beside the wall clock every region is bracketed by HIP events on
+the engine's streams (mt_timer_start / mt_timer_stop_async: from the idle device at the region's start to the end of its last
+kernel, reset or exchange, no host wait in between): `value_device_timeline` is the same throughput on that clock, i.e. without
+the host latency of the two fences, which at 8 GPUs x 131 072 arms is a third of a 20-step region.  The device time of a STEP
+is measured with HIP-event laps around the step launches only (mt_rollout may run a step as two concurrent launches on two
+streams that stay forked across calls; a lap ends when the last of them does; `roofline` says so).
 
 Prints ONE JSON line on rank 0 (contract: see the task brief / DESIGN.md section "Measurement").
 """
@@ -32,7 +43,6 @@ import argparse
 import json
 import math
 import os
-import re
 import sys
 import time
 
@@ -58,6 +68,14 @@ def actual_bytes_per_env_step(dof, k):
     """What mt_step_random really moves: the action is drawn in-kernel, so the 4D-byte action read of the
     SURVEY model does not happen (PMC traffic agrees: profiles/traffic.json)."""
     return algorithmic_bytes_per_env_step(dof, k) - 4 * dof
+
+
+def moved_bytes_per_env_step(dof, k, steps_per_launch=1.0):
+    """Bytes one env-step really moves when `steps_per_launch` consecutive steps share a launch (mt_rollout on small shards,
+    mt_rollout_fused): every step writes its outputs (obs 12K + reward 4 + done 1 + end effector 12); the state -- goals 4D,
+    targets 12K, alive mask 4, return 4 read; goals, alive mask, return written -- crosses once per LAUNCH.  One step per
+    launch gives actual_bytes_per_env_step()."""
+    return (12 * k + 17) + (8 * dof + 12 * k + 16) / float(steps_per_launch)
 
 
 def usable_cores():
@@ -179,20 +197,15 @@ def cpu_baseline(dof_table, k, budget_s=4.0, n=65536):
     }
 
 
-def measured_copy_bandwidth(torch, nbytes=1 << 30, reps=20):
-    """Device-to-device copy rate on this GPU (read + write bytes per second): the practical HBM ceiling that
-    SURVEY.md 8(d) asks to quote next to the 8 TB/s spec figure."""
-    src = torch.empty(nbytes // 4, dtype=torch.float32, device="cuda").normal_()
-    dst = torch.empty_like(src)
-    for _ in range(3):
-        dst.copy_(src)
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    ev0.record()
-    for _ in range(reps):
-        dst.copy_(src)
-    ev1.record()
-    torch.cuda.synchronize()
-    return 2.0 * nbytes * reps / (ev0.elapsed_time(ev1) * 1e-3) / 1e9
+def achievable_bandwidth(m, dof, k, n_envs, dev, reps=0):
+    """GB/s of the step's own access shape with no arithmetic (mt_stream_probe: the same rows read, rewritten and
+    nt-written per env, same addressing, one env per lane) over `n_envs` envs: the yardstick SURVEY.md 8(d) asks for next to
+    the 8 TB/s spec figure.  None where the probe is not built for (dof, k)."""
+    try:
+        us, nbytes = m.stream_probe(n_envs, dof, k, reps or max(20, min(400, int(2e8 // n_envs))), dev)
+    except (m.ManytorError, ValueError):
+        return None
+    return nbytes / (us * 1e-6) / 1e9
 
 
 def load_traffic(workload_key):
@@ -216,8 +229,10 @@ class EpisodeLoop:
 
     reset_first = False         # experiment switch (--reset-before-gather), see _episode_end
 
-    def __init__(self, engine, seed, episode_len, fused=False, overlap=True):
+    def __init__(self, engine, seed, episode_len, fused=False, overlap=True, steps_per_launch=1):
         self.eng, self.seed, self.L, self.fused, self.overlap = engine, seed, int(episode_len), fused, overlap
+        self.steps_per_launch = max(1, int(steps_per_launch))     # mt_rollout's k on small shards (engine.dispatch())
+        self.kernel_launches = 0    # kernel launches (per env range) behind the timed steps: ceil(segment / k), 1 per fused segment
         self.step = 0
         self.episode = 0
         self.gathers = 0
@@ -282,6 +297,7 @@ class EpisodeLoop:
             if time_kernels:
                 self.eng.lap_end("step")
                 launches += seg
+                self.kernel_launches += 1 if self.fused else -(-seg // self.steps_per_launch)
             self.step += seg
             done += seg
             if self.step % self.L == 0:
@@ -325,11 +341,24 @@ class TimedEngine:
         return out
 
 
-def time_step_launches(m, n, table, radius, k, dev, seed, fused=False, steps=600, episode_len=50):
+def time_step_launches(m, n, table, radius, k, dev, seed, fused=False, steps=600, episode_len=50, want_spl=False, rollout_k=None):
     """us per step of a secondary configuration: the same episode loop as the headline (reset every `episode_len`
-    steps, so the alive masks stay those of real episodes), pre-warmed, HIP events around the step launches only."""
-    e = TimedEngine(m.StepEngine(n, k, dh_table=table, radius=radius, device=dev))
-    loop = EpisodeLoop(e, seed, episode_len, fused=fused, overlap=False)
+    steps, so the alive masks stay those of real episodes), pre-warmed, HIP events around the step launches only.
+    rollout_k = 1 forces mt_rollout's one-launch-per-step form (MT_ROLLOUT_K, read by mt_create) where the default on this
+    batch size is k steps per launch.  -> (us, kernel name[, steps per kernel launch])."""
+    keep = os.environ.get("MT_ROLLOUT_K")
+    if rollout_k is not None:
+        os.environ["MT_ROLLOUT_K"] = str(rollout_k)
+    try:
+        raw = m.StepEngine(n, k, dh_table=table, radius=radius, device=dev)
+    finally:
+        if rollout_k is not None:
+            if keep is None:
+                os.environ.pop("MT_ROLLOUT_K", None)
+            else:
+                os.environ["MT_ROLLOUT_K"] = keep
+    e = TimedEngine(raw)
+    loop = EpisodeLoop(e, seed, episode_len, fused=fused, overlap=False, steps_per_launch=rollout_steps_per_launch(raw))
     t0 = time.perf_counter()
     while time.perf_counter() - t0 < 0.15:
         loop.run(4 * episode_len)
@@ -338,16 +367,19 @@ def time_step_launches(m, n, table, radius, k, dev, seed, fused=False, steps=600
     launches, _ = loop.run(steps, time_kernels=True)
     us = e.collect()["step"] * 1e3 / launches
     name = "rollout_kernel (fused)" if fused else e.step_kernel_name()
+    spl = launches / max(1, loop.kernel_launches)
     e.close()
-    return us, name
+    return (us, name, spl) if want_spl else (us, name)
 
 
 def time_loaded_action_steps(m, n, table, radius, k, dev, seed, steps=600, episode_len=50, chunk=10):
-    """us per mt_step launch when the actions come from HBM, as with a policy in the loop (step_kernel<SAMPLE = false>:
-    exactly SURVEY 8(d)'s byte model incl. the 4D-byte action read).  The actions of every step are written by
-    mt_sample_actions (a separate small launch), so the arms move as in the headline.  HIP-event laps around chunks of
-    `chunk` (sample, step) pairs, minus laps around chunks of `chunk` sample launches alone: a lap around every single
-    launch would add the cost of its two event records to a 40 us kernel."""
+    """us per mt_step when the actions come from HBM, as with a policy in the loop (step_kernel<SAMPLE = false>: exactly
+    SURVEY 8(d)'s byte model incl. the 4D-byte action read).  The actions of every step are written by mt_sample_actions (a
+    separate small launch), so the arms move as in the headline.  On a multi-chain handle both calls are issued per chain
+    (each half of the env range on its own stream, left forked from call to call).  HIP-event laps around chunks of `chunk`
+    (sample, step) pairs, minus laps around chunks of `chunk` sample launches alone in the same per-chain form: a lap
+    around every single launch would add the cost of its two event records to a 40 us kernel.
+    -> (us per step = pair - sample, us per sample launch, us per pair as timed, kernel name)."""
     e = m.StepEngine(n, k, dh_table=table, radius=radius, device=dev)
     t = 0
 
@@ -380,8 +412,11 @@ def time_loaded_action_steps(m, n, table, radius, k, dev, seed, steps=600, episo
             e.sample_actions(seed, rep * chunk + j)
         e.lap_end()
     us_sample = sum(e.lap_times()) * 1e3 / (steps // chunk * chunk)
+    d = e.dispatch()["chains"]
+    name = e.step_kernel_name().split(" [mt_rollout")[0].replace("step_kernel<", "step_kernel<SAMPLE=false, ") + \
+        (f" [mt_step: {d['count']} chains of {d['span']} envs]" if d["count"] > 1 else "")
     e.close()
-    return us_pair - us_sample, us_sample
+    return us_pair - us_sample, us_sample, us_pair, name
 
 
 class Fabric:
@@ -428,14 +463,24 @@ class Fabric:
         return bool(int(t.item()))
 
 
+def rollout_steps_per_launch(raw):
+    """k of mt_rollout on this engine (1 = one launch per step), from mt_describe_dispatch."""
+    try:
+        return int(raw.dispatch()["rollout"]["steps_per_launch"])
+    except (AttributeError, KeyError):
+        return 1
+
+
 def measure(fab, raw, n_total, steps, warmup, episode_len, seed, fused=False, overlap=True, repeats=0, prewarm_s=PREWARM_S,
             min_timed_s=MIN_TIMED_S):
     """The timing protocol of the contract on one engine (this rank's shard; gather already attached): time-based
     pre-warm, `warmup` untimed steps, then `repeats` regions of EXACTLY `steps` steps, each bracketed by fence() on both
-    sides; the region time is the max over ranks, the figure the median region.  Returns a dict of raw numbers."""
+    sides; the region time is the max over ranks, the figure the median region.  Every region is also bracketed by HIP
+    events on the engine's streams (device idle after the opening fence -> end of the region's last kernel / reset /
+    exchange): `region_device_ms`, max over ranks, median.  Returns a dict of raw numbers."""
     eng = TimedEngine(raw)
     L = max(1, min(episode_len, steps))                         # >= 1 gather inside every timed region
-    loop = EpisodeLoop(eng, seed, L, fused=fused, overlap=overlap)
+    loop = EpisodeLoop(eng, seed, L, fused=fused, overlap=overlap, steps_per_launch=rollout_steps_per_launch(raw))
     prewarm = 0
     fab.fence(raw)
     t0 = time.perf_counter()
@@ -448,14 +493,17 @@ def measure(fab, raw, n_total, steps, warmup, episode_len, seed, fused=False, ov
     loop.run(warmup)                                            # the W untimed warm-up steps of the contract
     loop.align()                                                # the first timed region starts an episode
     fab.fence(raw)
-    regions, kernel_ms, gather_ms, launches, gathers = [], 0.0, 0.0, 0, 0
+    regions, device_ms, kernel_ms, gather_ms, launches, gathers = [], [], 0.0, 0.0, 0, 0
     for _ in range(reps):
         eng.start_region()
         fab.fence(raw)
+        raw.timer_start()                                       # start mark on the idle device (ahead of the host clock)
         t0 = time.perf_counter()
         ln, gt = loop.run(steps, time_kernels=True)
+        raw.timer_stop_async()                                  # end marks behind everything queued; no join, no host wait
         fab.fence(raw)
         regions.append(time.perf_counter() - t0)
+        device_ms.append(raw.timer_read())
         ms = eng.collect()
         kernel_ms += ms["step"]
         # overlapped: device time of the region's last exchange on the side stream; in line: HIP-event laps around it
@@ -463,6 +511,7 @@ def measure(fab, raw, n_total, steps, warmup, episode_len, seed, fused=False, ov
         launches += ln
         gathers += gt
     regions = fab.max_over_ranks(regions)                       # a region takes as long as its slowest rank
+    device_ms = fab.max_over_ranks(device_ms)
     # sanity on what was computed (not timed): returns are small integers, every rank's shard arrived
     tr = raw.total_reward()
     assert np.isfinite(tr).all() and np.all(tr == np.round(tr))
@@ -470,10 +519,100 @@ def measure(fab, raw, n_total, steps, warmup, episode_len, seed, fused=False, ov
     g = loop.gathered.cpu().numpy()
     assert np.all(g == np.round(g)) and np.abs(g).max() <= L    # returns of an L-step episode
     elapsed = float(np.median(regions))
+    dev_s = float(np.median(device_ms)) * 1e-3
     return {"elapsed": elapsed, "ms_per_step": elapsed / steps * 1e3, "ms_per_step_min": float(regions.min()) / steps * 1e3,
             "ms_per_step_max": float(regions.max()) / steps * 1e3, "step_us": kernel_ms * 1e3 / max(1, launches),
             "launches": launches, "gather_us": gather_ms * 1e3 / max(1, gathers), "gathers_per_region": gathers // reps,
-            "repeats": reps, "prewarm": prewarm, "episode_len": L, "value": n_total * steps / elapsed}
+            "repeats": reps, "prewarm": prewarm, "episode_len": L, "value": n_total * steps / elapsed,
+            "region_device_ms": dev_s * 1e3, "device_ms_per_step": dev_s * 1e3 / steps,
+            "value_device_timeline": n_total * steps / max(dev_s, 1e-12),
+            "steps_per_kernel_launch": launches / max(1, loop.kernel_launches)}
+
+
+def self_launch(argv, gpus, dry_run=False, timeout_s=1800.0, script=None):
+    """--gpus N > 1 without a launcher: start N fresh children of this script, one rank per GPU (what `python -m
+    torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1` would export), relay rank 0's JSON line to
+    stdout and everything else to stderr, and return the worst exit code.  Called BEFORE anything imports torch or touches
+    HIP (a process that has initialised the GPU must not start replacing or duplicating itself); children are plain
+    subprocess.Popen of a new interpreter -- no exec of this process, no fork of GPU state.  The first failing rank, or the
+    timeout, ends the whole group."""
+    import signal
+    import socket
+    import subprocess
+    with socket.socket() as sock:                               # a free rendezvous port
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    script = os.path.abspath(script or __file__)
+    plans = []
+    for r in range(gpus):
+        env = {"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(gpus), "LOCAL_WORLD_SIZE": str(gpus),
+               "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY":
+               os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")}
+        plans.append({"argv": [sys.executable, script] + [a for a in argv if a != "--launch-dry-run"], "env": env})
+    if dry_run:
+        print(json.dumps({"launcher": "bench.py self_launch", "children": plans}))
+        return 0
+    procs, out0, reader = [], [], None
+    worst, why = 0, None
+    try:
+        for r, pl in enumerate(plans):
+            procs.append(subprocess.Popen(pl["argv"], env={**os.environ, **pl["env"]}, cwd=os.getcwd(),
+                                          stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr,
+                                          start_new_session=True))
+        import threading
+        reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
+        reader.start()
+        deadline = time.monotonic() + timeout_s
+        live = set(range(gpus))
+        while live and why is None:
+            for r in sorted(live):
+                rc = procs[r].poll()
+                if rc is None:
+                    continue
+                live.discard(r)
+                if rc != 0:
+                    worst, why = (rc if rc > 0 else 128 - rc), f"rank {r} exited with {rc}"
+                    break
+            if why is None and live and time.monotonic() > deadline:
+                worst, why = 124, f"timeout after {timeout_s:.0f} s"
+            if live and why is None:
+                time.sleep(0.05)
+        if why is not None:
+            print(f"[bench launcher] {why}: ending the other ranks", file=sys.stderr)
+    finally:
+        # whoever is still alive here (a failure, the timeout, an interrupt of the launcher) goes, group by group: each
+        # child leads its own session / process group.  After a normal end nobody is.
+        for sig, wait_s in ((signal.SIGTERM, 10.0), (signal.SIGKILL, 5.0)):
+            alive = [q for q in procs if q.poll() is None]
+            if not alive:
+                break
+            for q in alive:
+                try:
+                    os.killpg(q.pid, sig)
+                except (ProcessLookupError, PermissionError):
+                    pass
+            t_end = time.monotonic() + wait_s
+            while time.monotonic() < t_end and any(q.poll() is None for q in alive):
+                time.sleep(0.05)
+    if reader is not None:
+        reader.join(timeout=10.0)
+    text = (out0[0] if out0 else b"").decode(errors="replace")
+    line = None
+    for ln in text.splitlines():
+        try:
+            if isinstance(json.loads(ln), dict) and "metric" in ln:
+                line = ln
+                continue
+        except ValueError:
+            pass
+        print(ln, file=sys.stderr)
+    if line is not None:
+        sys.stdout.write(line + "\n")
+        sys.stdout.flush()
+    elif worst == 0:
+        print("[bench launcher] rank 0 printed no JSON line", file=sys.stderr)
+        worst = 1
+    return worst
 
 
 def main():
@@ -481,11 +620,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--envs-per-gpu", type=int, default=1048576, help="weak scaling (default): arms owned by every GPU")
+    ap.add_argument("--envs-per-gpu", type=int, default=0,
+                    help="weak scaling: arms owned by every GPU, as the headline (the default headline is 1 048 576 arms in "
+                         "all: on one GPU that is the same job; with N > 1 the weak leg is in `secondary`)")
     ap.add_argument("--envs-total", type=int, default=0,
-                    help="strong scaling: total arms, sharded over the GPUs (--gpus 8 --envs-total 4194304 = "
-                         "BASELINE.json configs[3]; --envs-total 1048576 = the north-star curve).  With N > 1 both are "
-                         "also run as secondary legs of the default (weak) invocation")
+                    help="strong scaling: total arms, sharded over the GPUs, as the headline (default 1 048 576 = the metric's "
+                         "workload; --gpus 8 --envs-total 4194304 = BASELINE.json configs[3], which an N > 1 run also "
+                         "reports as a secondary leg)")
     ap.add_argument("--dof", type=int, default=4, choices=(4, 7))
     ap.add_argument("--targets", type=int, default=7)
     ap.add_argument("--episode-len", type=int, default=50)       # test_multi.py:8
@@ -514,6 +655,9 @@ def main():
     ap.add_argument("--single-device", action="store_true",
                     help="testing only: every rank on GPU 0 (with MT_RCCL_LIB pointing at the stand-in transport of "
                          "tests/fake_rccl this runs the whole N > 1 product path on a one-GPU box)")
+    ap.add_argument("--launch-dry-run", action="store_true",
+                    help="print what the launcher would start for --gpus N (argv and rank environment of every child) and exit")
+    ap.add_argument("--launch-timeout", type=float, default=1800.0, help="seconds the self-launched ranks get in all")
     ap.add_argument("--hw-trig", action="store_true")
     ap.add_argument("--dh-in-lds", action="store_true")
     ap.add_argument("--direct-trig", action="store_true")
@@ -524,6 +668,13 @@ def main():
     ap.add_argument("--ablate", type=int, default=0, help="diagnostic builds (results invalid): 1 skip interior "
                     "sub-steps, 2 also skip the observation math")
     args = ap.parse_args()
+
+    # --gpus N without a launcher: this process only starts the ranks (nothing above this line has touched torch or HIP)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(sys.argv[1:], args.gpus, args.launch_dry_run, args.launch_timeout))
+    if args.launch_dry_run:
+        print(json.dumps({"launcher": "none (one rank, or WORLD_SIZE already set by a launcher)", "children": []}))
+        return
 
     # The contract is ONE JSON line on stdout.  Native libraries loaded below write there too (RCCL prints a version
     # banner when its first multi-rank communicator is built, gloo its connection report), so fd 1 is pointed at
@@ -545,7 +696,7 @@ def main():
     EpisodeLoop.phase = args.episode_phase if args.episode_phase >= 0 else (0 if args.gpus == 1 else min(args.episode_len, args.steps) // 2)
     rank, local_rank, world = D.env_from_torchrun()
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher started a different number of ranks")
     if not torch.cuda.is_available() or m.device_count() < 1:
         raise SystemExit("bench.py needs a GPU: the step path has no CPU fallback")
     # one process per GPU: LOCAL_RANK names the device, unless the launcher already narrowed every process's view to
@@ -628,34 +779,58 @@ def main():
                 "overlapped: snapshot (per chain) + exchange on the engine's side stream (mt_gather_returns_begin), beside "
                 "the reset and the next episode's steps")
 
-    def secondary_leg(n_total, label):
-        """A further (strong-scaling) configuration on the same ranks: fresh engines + ONE communicator of their own, the
-        same episode loop, real gather and fences as the headline (shorter pre-warm), first as per-step launches, then --
-        same engines, same communicator -- as fused segments."""
-        raw, n_local, fallback = make_engine(n_total, True)
+    def regime_of(n_local, bytes_per_env):
+        mb = bytes_per_env * n_local / 1e6
+        if mb < 150:
+            return ("on-die: the %.0f MB a step touches fit the L2s + the 256 MiB Infinity Cache, the step is bound by the "
+                    "kernel boundary and the dependent arithmetic of a few waves per SIMD, not by HBM" % mb)
+        if mb < 400:
+            return ("HBM + Infinity Cache: the %.0f MB a step touches are about the size of the 256 MiB MALL, so part of the "
+                    "re-read state is served on-die; the pure-HBM point is the 4 194 304-arm row" % mb)
+        return "HBM (working set of %.0f MB per step, beyond the Infinity Cache)" % mb
+
+    def leg_record(r, f, n_total, n_local, strong, label, name, fallback):
+        """What every leg of an N > 1 line reports (and the N > 1 headline inside `secondary.headline_detail`)."""
+        moved = moved_bytes_per_env_step(args.dof, args.targets, r["steps_per_kernel_launch"])
+        rec = {"what": label, "scaling": "strong" if strong else "weak", "envs_total": n_total, "envs_on_rank0": n_local,
+               "n_gpus": world, "value": r["value"], "value_device_timeline": r["value_device_timeline"], "unit": "env-steps/s",
+               "ms_per_step": r["ms_per_step"], "ms_per_step_min": r["ms_per_step_min"], "ms_per_step_max": r["ms_per_step_max"],
+               "device_ms_per_step": r["device_ms_per_step"],
+               "avg_kernel_us": r["step_us"], "kernel": name, "steps_per_kernel_launch": r["steps_per_kernel_launch"],
+               "gather_us": r["gather_us"], "gathers_in_timed_region": r["gathers_per_region"], "repeats": r["repeats"],
+               "episode_len": r["episode_len"], "episode_phase": EpisodeLoop.phase % r["episode_len"],
+               "collective": describe_collective(fallback), "gather_mode": gather_mode(fallback),
+               # per-GPU fraction of the HBM peak while a step is on the device, on the bytes the launches really move
+               "bytes_per_env_step": moved,
+               "frac_of_hbm_peak_per_gpu": moved * n_local / (r["step_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
+               "regime": regime_of(n_local, moved)}
+        if f is not None:
+            rec["fused"] = {"value": f["value"], "value_device_timeline": f["value_device_timeline"], "ms_per_step": f["ms_per_step"],
+                            "device_ms_per_step": f["device_ms_per_step"], "avg_kernel_us": f["step_us"],
+                            "gather_us": f["gather_us"], "gathers_in_timed_region": f["gathers_per_region"],
+                            "kernel": "rollout_kernel (mt_rollout_fused: one launch per episode segment)", "repeats": f["repeats"]}
+            rec["fused_us_per_step"] = f["step_us"]
+        return rec
+
+    def secondary_leg(n_total, strong, label):
+        """A further configuration on the same ranks: fresh engines + ONE communicator of their own, the same episode loop,
+        real gather and fences as the headline (shorter pre-warm), first through mt_rollout, then -- same engines, same
+        communicator -- as fused segments."""
+        raw, n_local, fallback = make_engine(n_total, strong)
         kw = dict(overlap=not args.sync_gather, prewarm_s=0.15, min_timed_s=0.03)
         r = measure(fab, raw, n_total, args.steps, args.warmup, args.episode_len, args.seed, fused=False, **kw)
         f = measure(fab, raw, n_total, args.steps, args.warmup, args.episode_len, args.seed, fused=True, **kw)
         name = raw.step_kernel_name()
         raw.close()
-        return {"what": label, "scaling": "strong", "envs_total": n_total, "envs_on_rank0": n_local, "n_gpus": world,
-                "value": r["value"], "unit": "env-steps/s", "ms_per_step": r["ms_per_step"],
-                "ms_per_step_min": r["ms_per_step_min"], "ms_per_step_max": r["ms_per_step_max"],
-                "avg_kernel_us": r["step_us"], "kernel": name, "gather_us": r["gather_us"],
-                "gathers_in_timed_region": r["gathers_per_region"], "repeats": r["repeats"], "episode_len": r["episode_len"],
-                "episode_phase": EpisodeLoop.phase % r["episode_len"], "collective": describe_collective(fallback), "gather_mode": gather_mode(fallback),
-                # per-GPU fraction of the HBM peak while a step is on the device
-                "frac_of_hbm_peak_per_gpu": bpe_actual * n_local / (r["step_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                "bytes_per_env_step": bpe_actual,
-                "fused": {"value": f["value"], "ms_per_step": f["ms_per_step"], "avg_kernel_us": f["step_us"],
-                          "gather_us": f["gather_us"], "gathers_in_timed_region": f["gathers_per_region"],
-                          "kernel": "rollout_kernel (mt_rollout_fused: one launch per episode segment)",
-                          "repeats": f["repeats"]},
-                "fused_us_per_step": f["step_us"]}
+        return leg_record(r, f, n_total, n_local, strong, label, name, fallback)
 
-    # ---- the headline: weak scaling (per-GPU work fixed) unless --envs-total ------------------------------------
-    strong = args.envs_total > 0
-    n_total = args.envs_total if strong else args.envs_per_gpu * world
+    # ---- the headline: the metric's workload -- 1 048 576 arms in all -- unless --envs-total / --envs-per-gpu ----------
+    if args.envs_total > 0:
+        strong, n_total = True, args.envs_total
+    elif args.envs_per_gpu > 0:
+        strong, n_total = False, args.envs_per_gpu * world
+    else:
+        strong, n_total = world > 1, 1048576     # one GPU: strong and weak are the same job (reported as "weak", as before)
     raw, n_local, gather_fallback = make_engine(n_total, strong)
     r = measure(fab, raw, n_total, args.steps, args.warmup, args.episode_len, args.seed, fused=args.fused,
                 overlap=not args.sync_gather, repeats=args.repeats)
@@ -663,15 +838,18 @@ def main():
         print("ABLATION BUILD: timings only, outputs are not the reference's", file=sys.stderr)
     L = r["episode_len"]
     kernel_name = raw.step_kernel_name()
+    dispatch = raw.dispatch()
     raw.close()
 
     out = None
     if rank == 0:
         step_s = r["step_us"] * 1e-6                            # device time of one step of this rank's envs (HIP events)
-        # mt_rollout may run a step as several concurrent launches on env ranges (the kernel name says so)
-        mm = re.search(r"\[mt_rollout: (\d+) chains of (\d+) envs", kernel_name)
-        chains, envs_per_launch = (int(mm.group(1)), int(mm.group(2))) if (mm and not args.fused) else (1, n_local)
-        achieved = bpe_actual * n_local / step_s / 1e9
+        # mt_rollout may run a step as several concurrent launches on env ranges (the dispatch says so)
+        chains = 1 if args.fused else int(dispatch["chains"]["count"])
+        envs_per_launch = n_local if chains == 1 else int(dispatch["chains"]["span"])
+        spl = r["steps_per_kernel_launch"]                      # 1 = one launch per step; L for --fused; k on small shards
+        moved = moved_bytes_per_env_step(args.dof, args.targets, spl)
+        achieved = moved * n_local / step_s / 1e9
         achieved_model = bpe * n_local / step_s / 1e9
         trig = 2 if args.hw_trig else (1 if args.direct_trig else 0)
         static = not (args.no_specialize or args.dh_in_lds)
@@ -679,56 +857,68 @@ def main():
         variant = "+".join(v for v, on in (("recurrence", trig == 0), ("direct_trig", trig == 1), ("hw_trig", trig == 2),
                                            ("static_table", static), ("runtime_table", not static),
                                            ("dh_in_lds", args.dh_in_lds)) if on)
-        workload = f"{n_local} arms/GPU x {world} GPU, {args.dof}-DoF DH chain, K={args.targets} targets, " \
+        workload = f"{n_total} arms in all = {n_local} arms/GPU x {world} GPU, {args.dof}-DoF DH chain, K={args.targets} targets, " \
                    f"25 sub-steps, random integer-degree actions drawn in-kernel, episode {L} steps"
-        working_set_mb = bpe_actual * n_local / 1e6
+        # the streaming yardstick of the step's own access shape: pure HBM (4 M envs, ~1 GB per pass) and at this size
+        ach_hbm = achievable_bandwidth(m, args.dof, args.targets, 4194304, dev)
+        ach_same = achievable_bandwidth(m, args.dof, args.targets, max(256, n_local), dev)
         out = {
             "metric": METRIC, "value": r["value"], "unit": "env-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": r["ms_per_step"],
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
+            "value_device_timeline": r["value_device_timeline"], "device_ms_per_step": r["device_ms_per_step"],
             "config": {"workload": workload, "envs_per_gpu": n_local, "envs_total": n_total, "dof": args.dof,
                        "targets": args.targets, "substeps": 25, "episode_len": L, "episode_phase": EpisodeLoop.phase % L,
                        "collective": describe_collective(gather_fallback),
                        "kernel_variant": variant, "prewarm_launches": r["prewarm"], "repeats": r["repeats"],
                        "gathers_in_timed_region": r["gathers_per_region"], "gather_mode": gather_mode(gather_fallback),
+                       "launcher": os.environ.get("TORCHELASTIC_RUN_ID") and "torch.distributed.run" or
+                                   ("bench.py self_launch (one fresh child process per rank)" if world > 1 else "none (one process)"),
                        "timing": "median over `repeats` regions of exactly `steps` steps, each bracketed by barrier + "
-                                 "torch.cuda.synchronize(), max over ranks",
+                                 "torch.cuda.synchronize(), max over ranks; value_device_timeline = the same regions on the "
+                                 "device's clock (HIP events from the idle device at the region's start to the end of its "
+                                 "last kernel / reset / exchange, max over ranks, median)",
                        "barrier": "none (one rank)" if world == 1 else
                                   ("device drained, then a shared-memory barrier between the node's ranks "
                                    "(manytor_amd.distributed.HostBarrier)" if host_barrier is not None else
-                                   "device drained, then torch.distributed barrier")},
+                                   "device drained, then torch.distributed barrier"),
+                       "dispatch": {k: dispatch[k] for k in ("step", "chains", "rollout", "fused", "reset", "overrides")}},
             "ms_per_step_min": r["ms_per_step_min"], "ms_per_step_max": r["ms_per_step_max"],
             "gather_us": r["gather_us"],
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": load_traffic(f"d{args.dof}_k{args.targets}_n{n_local}"),
+                "traffic": load_traffic(f"d{args.dof}_k{args.targets}_n{n_local}") if spl == 1 else None,
                 "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, committed under "
                                   "profiles/ (traffic.json); not re-measured in this run",
                 "kernel": (f"rollout_kernel<{table_name}> ({L} steps per launch; us per step quoted)" if args.fused else
                            kernel_name + " (action drawn in-kernel)"),
-                "bytes_per_env_step": bpe_actual, "avg_kernel_us": r["step_us"], "steps_timed": r["launches"],
+                "bytes_per_env_step": moved, "avg_kernel_us": r["step_us"], "steps_timed": r["launches"],
+                "steps_per_kernel_launch": spl,
                 "launches_per_step": chains, "envs_per_launch": envs_per_launch,
-                "bytes_per_launch": bpe_actual * envs_per_launch, "bytes_per_step": bpe_actual * n_local,
+                "bytes_per_launch": moved * spl * envs_per_launch, "bytes_per_step": moved * n_local,
                 "bytes_per_env_step_survey_model": bpe, "achieved_survey_model": achieved_model,
                 "frac_survey_model": achieved_model / HBM_PEAK_GBS,
-                "regime": ("HBM + Infinity Cache: the %.0f MB a step touches are about the size of the 256 MiB MALL, so part "
-                           "of the re-read state is served on-die; the pure-HBM point is secondary.other_configs['4194304 "
-                           "arms ...']" % working_set_mb) if working_set_mb < 400 else "HBM (working set beyond the Infinity Cache)",
-                "note": "achieved / frac use the bytes the timed kernel really moves per env-step (SURVEY 8(d)'s 12 D + 24 K + "
-                        "33 minus the 4 D-byte action read it does not do: the action is drawn in registers and IS the new "
-                        "goals); *_survey_model are the same with SURVEY's own figure.  avg_kernel_us = device time of ONE "
-                        "STEP of this rank's envs (bytes_per_step) by HIP events around the step launches, fork and join of "
-                        "the chains included.  With launches_per_step = 2 a step is two CONCURRENT launches of "
-                        "envs_per_launch envs on two streams: rocprofv3's per-launch average (34.7 us for 524 288 envs, "
-                        "profiles/r03_kernel_stats_by_grid.csv) is then the duration of each of two overlapping kernels, "
-                        "not half a step; the union of their intervals per step (35.7 us, same file, last line) is the "
-                        "figure that corresponds to avg_kernel_us",
+                "achievable_gbs": ach_hbm,
+                "achievable_note": "mt_stream_probe: the memory operations of one step (same rows read / rewritten / nt-written "
+                                   "per env, same addressing, one env per lane) with no arithmetic, over 4 194 304 envs "
+                                   "(0.98 GB per pass: pure HBM) -- what this access shape reaches on this box; "
+                                   "achievable_gbs_same_size is the same probe over envs_per_gpu envs (one launch)",
+                "achievable_gbs_same_size": ach_same,
+                "frac_of_achievable_same_size": (achieved / ach_same) if ach_same else None,
+                "regime": regime_of(n_local, moved),
+                "note": "achieved / frac use the bytes the timed launches really move per env-step: SURVEY 8(d)'s 12 D + 24 K + "
+                        "33 minus the 4 D-byte action read that does not happen (the action is drawn in registers and IS the "
+                        "new goals), and -- when mt_rollout runs k steps per launch (steps_per_kernel_launch > 1: small shards) "
+                        "-- the state rows once per launch instead of once per step; *_survey_model are the same time with "
+                        "SURVEY's own 249-byte figure.  avg_kernel_us = device time of ONE STEP of this rank's envs by HIP "
+                        "events around the step launches, fork and join of the chains included.  With launches_per_step = 2 a "
+                        "step is two CONCURRENT launches of envs_per_launch envs on two streams: rocprofv3's per-launch "
+                        "average is then the duration of each of two overlapping kernels, not half a step; the union of "
+                        "their intervals per step (tools/trace_summary.py --union) corresponds to avg_kernel_us",
             },
         }
-        if world == 1:
-            out["roofline"]["measured_copy_gbs"] = measured_copy_bandwidth(torch)
     secondary = world == 1 and not args.fused and not args.ablate and not args.no_secondary
     if secondary and rank == 0:
         # informational, not the headline: the same episodes as ONE launch each
@@ -737,14 +927,17 @@ def main():
             "env_steps_per_s": n_local / (us * 1e-6), "us_per_step": us, "steps_per_launch": 50,
             "note": "mt_rollout_fused: state stays in registers/LDS between steps, bit-identical results; "
                     "arithmetic-bound, so the per-step byte model does not apply"}}
-        us, us_sample = time_loaded_action_steps(m, n_local, table, radius, args.targets, dev, args.seed)
+        us, us_sample, us_pair, lname = time_loaded_action_steps(m, n_local, table, radius, args.targets, dev, args.seed)
         out["secondary"]["loaded_action_step"] = {
-            "us_per_step": us, "sample_actions_us": us_sample,
+            "us_per_step": us, "sample_actions_us": us_sample, "pair_us": us_pair, "kernel": lname,
             "env_steps_per_s": n_local / (us * 1e-6), "bytes_per_env_step": bpe,
             "frac_of_hbm_peak": bpe * n_local / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+            "frac_of_hbm_peak_pair": (bpe + 4 * args.dof) * n_local / (us_pair * 1e-6) / 1e9 / HBM_PEAK_GBS,
             "note": "mt_step with the actions read from HBM (policy-in-the-loop shape, step_kernel<SAMPLE = false>): "
-                    "the kernel that moves exactly the SURVEY 8(d) bytes; the actions are written by a separate "
-                    "mt_sample_actions launch whose own time (sample_actions_us) is subtracted"}
+                    "the kernel that moves exactly the SURVEY 8(d) bytes, issued per chain like mt_rollout's steps; the "
+                    "actions are written by a separate mt_sample_actions launch (per chain as well) whose own time "
+                    "(sample_actions_us, measured in the same per-chain form) is subtracted; *_pair = the (sample, step) pair "
+                    "as timed, against the bytes of both launches (SURVEY's 249 + the 4 D-byte action write)"}
         # BASELINE.json's other single-GPU configurations and the pure-HBM point, same kernel path, short runs
         out["secondary"]["other_configs"] = {}
         for label, n2, tbl, rad in (("configs[1]: 65536 arms, 4-DoF", 65536, m.REF_DH_TABLE, 51.3),
@@ -752,33 +945,51 @@ def main():
                                     ("524288 arms, 4-DoF (configs[3] over 8 GPUs, per-GPU shard)", 524288, m.REF_DH_TABLE, 51.3),
                                     ("4194304 arms, 4-DoF (1 GB working set: pure HBM regime)", 4194304, m.REF_DH_TABLE, 51.3),
                                     ("configs[4]: 1048576 arms, 7-DoF table", 1048576, m.DH7_TABLE, 92.6)):
-            us, kname = time_step_launches(m, n2, tbl, rad, args.targets, dev, args.seed,
-                                           steps=300 if n2 > (1 << 21) else 600)
+            us, kname, spl2 = time_step_launches(m, n2, tbl, rad, args.targets, dev, args.seed,
+                                                 steps=300 if n2 > (1 << 21) else 600, want_spl=True)
             b2 = algorithmic_bytes_per_env_step(len(tbl), args.targets)
-            b2a = actual_bytes_per_env_step(len(tbl), args.targets)
-            out["secondary"]["other_configs"][label] = {
-                "us_per_step": us, "kernel": kname, "env_steps_per_s": n2 / (us * 1e-6),
-                "bytes_per_env_step": b2a, "frac_of_hbm_peak": b2a * n2 / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                "bytes_per_env_step_survey_model": b2,
-                "frac_survey_model": b2 * n2 / (us * 1e-6) / 1e9 / HBM_PEAK_GBS}
+            b2a = moved_bytes_per_env_step(len(tbl), args.targets, spl2)
+            gbs = b2a * n2 / (us * 1e-6) / 1e9
+            rec = {"us_per_step": us, "kernel": kname, "env_steps_per_s": n2 / (us * 1e-6), "steps_per_kernel_launch": spl2,
+                   "bytes_per_env_step": b2a, "frac_of_hbm_peak": gbs / HBM_PEAK_GBS,
+                   "bytes_per_env_step_survey_model": b2,
+                   "frac_survey_model": b2 * n2 / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, "regime": regime_of(n2, b2a)}
+            if spl2 > 1:    # the pure one-launch-per-step figure beside the k-steps-per-launch default (MT_ROLLOUT_K=1)
+                us1, kname1 = time_step_launches(m, n2, tbl, rad, args.targets, dev, args.seed, steps=600, rollout_k=1)
+                rec["one_launch_per_step"] = {"us_per_step": us1, "kernel": kname1, "env_steps_per_s": n2 / (us1 * 1e-6),
+                                              "bytes_per_env_step": actual_bytes_per_env_step(len(tbl), args.targets)}
+            if n2 == 4194304 and len(tbl) == args.dof and out["roofline"]["achievable_gbs"]:
+                rec["achievable_gbs"] = out["roofline"]["achievable_gbs"]
+                rec["frac_of_achievable"] = gbs / out["roofline"]["achievable_gbs"]
+            out["secondary"]["other_configs"][label] = rec
     if world > 1 and not args.fused and not args.ablate and not args.no_secondary:
-        # One N > 1 invocation yields every figure BASELINE.json's north_star names: next to the (weak) headline, the
-        # 1 M-arm job and configs[3] (4 194 304 arms) SHARDED over these ranks, per-step launches and fused segments.
-        # Collective code: every rank runs every leg.
+        # One N > 1 invocation yields every figure BASELINE.json's north_star names: the headline is the metric's 1 M arms
+        # sharded over these ranks; here the weak leg (1 M arms PER GPU) and configs[3] (4 194 304 arms sharded), each
+        # through mt_rollout and as fused segments.  Collective code: every rank runs every leg.
         legs = {}
-        for key, nt, label in (("strong_1m", 1048576, "north_star: 1 048 576 arms sharded over the GPUs (the 1 -> N curve)"),
-                               ("config3", 4194304, "BASELINE.json configs[3]: 4 194 304 arms sharded over the GPUs")):
-            if strong and nt == n_total:
+        for key, nt, st, label in (("strong_1m", 1048576, True, "north_star: 1 048 576 arms sharded over the GPUs (the 1 -> N curve)"),
+                                   ("weak_1m_per_gpu", 1048576 * world, False, "weak scaling: 1 048 576 arms per GPU"),
+                                   ("config3", 4194304, True, "BASELINE.json configs[3]: 4 194 304 arms sharded over the GPUs")):
+            if nt == n_total and (st == strong or nt % world == 0):
                 continue                                        # that IS the headline of this invocation
-            leg = secondary_leg(nt, label)
-            legs[key] = leg
+            legs[key] = secondary_leg(nt, st, label)
         if rank == 0:
             out["secondary"] = legs
-            out["secondary"]["note"] = ("`value` of the JSON line is the weak-scaling headline (scaling = weak: per-GPU work "
-                                        "fixed); each leg here states its own scaling")
-    if rank == 0:
-        if world == 1 and not args.no_cpu_baseline:
+            out["secondary"]["note"] = ("`value` of the JSON line is the leg named in config.workload (default: the metric's "
+                                        "1 048 576 arms sharded over the GPUs, scaling = strong); each leg here states its own "
+                                        "scaling.  value = wall clock of the fenced regions; value_device_timeline = the same "
+                                        "regions on the device's clock (what the GPUs sustain once the host's fences are out "
+                                        "of the picture: a learner that does not fence every 20 steps sees this one)")
+    if not args.no_cpu_baseline:
+        # rank 0 times the CPU ports (every host core it may use); its peers wait asleep, not spinning on those cores
+        if rank == 0:
             out["cpu_baseline"] = cpu_baseline(table, args.targets)
+        if world > 1:
+            if host_barrier is not None:
+                host_barrier.wait(timeout_s=1800.0, sleep_s=0.02)
+            else:
+                dist.barrier()
+    if rank == 0:
         os.write(json_fd, (json.dumps(out) + "\n").encode())
 
     if host_barrier is not None:

@@ -40,7 +40,7 @@ extern "C" {
 #define MT_API
 #endif
 
-#define MT_VERSION 300          /* major*10000 + minor*100 + patch */
+#define MT_VERSION 400          /* major*10000 + minor*100 + patch */
 #define MT_MAX_DOF 8
 #define MT_MAX_TARGETS 32
 #define MT_MAX_RETURN_RING 64
@@ -144,6 +144,11 @@ MT_API int mt_destroy(mt_handle h);
  * at mt_create; every schedule gives the same bits): e.g. "step_kernel<Ref4Table, trig=0, lds=false, pf=8>",
  * "step_split_kernel<RtTable<5>, L=4>".  For benchmark records and profiles; valid until the next call on the handle. */
 MT_API const char* mt_step_kernel_name(mt_handle h);
+/* The dispatch of this handle as data: a JSON object with the schedule resolved for every entry point ("step",
+ * "chains", "rollout", "fused", "reset"), the MT_* environment overrides that were in effect at mt_create ("overrides")
+ * and the library's one table of size thresholds ("policy": engine.hip kPolicy).  Tests assert regimes from it instead
+ * of parsing kernel names; valid until the next mt_describe_dispatch on the handle. */
+MT_API const char* mt_describe_dispatch(mt_handle h);
 /* Run on a caller-owned hipStream_t (e.g. torch's current stream), so that the handle's launches are ordered with
  * the caller's own work on that stream.  NULL means what it means to HIP: the legacy default stream (which is what
  * torch's default stream is).  mt_use_own_stream goes back to the handle's private non-blocking stream, which is
@@ -180,6 +185,11 @@ MT_API int mt_sample_actions(mt_handle h, uint64_t seed, uint32_t step_idx);
 
 /* Environment.step() = get_observations() side effect + action() + return
  * accumulation + is_done(), manytor.py:255-260, :175-213, for all envs, one launch. */
+/* On a multi-chain handle (163 840 .. 3 M envs, see mt_rollout) the step is two launches, one per half of the env range on
+ * its own stream; mt_set_actions from DEVICE memory and mt_sample_actions stage each half's rows on the same streams, so on
+ * the handle's own stream a policy loop (set actions / step / ...) keeps the halves independent from call to call (any
+ * other call and mt_sync fold them back), and on a caller's stream every call forks behind the caller's work and joins
+ * before it returns.  Same bits as the single launch. */
 MT_API int mt_step(mt_handle h);
 /* One host round trip of Multienv.step (manytor.py:115-122): (N, D) host actions in, obs2 (N, 3K) f32, reward (N,)
  * i32 and done (N,) u8 out, through one page-locked staging buffer and ONE stream synchronisation (instead of the
@@ -197,8 +207,12 @@ MT_API int mt_bad_action_count(mt_handle h, uint64_t* count);
  * step, manytor.py:184), which saves 4*D bytes of traffic per env. */
 MT_API int mt_step_random(mt_handle h, uint64_t seed, uint32_t step_idx);
 /* n_steps x mt_step_random with step indices step_idx0, step_idx0+1, ... (the
- * inner loop of test_multi.py:19-21).  On small batches (<= 131 072 envs) the launches are replayed from a HIP graph
- * that the handle captures once per segment length: the same kernels, the same results, less time per kernel boundary.
+ * inner loop of test_multi.py:19-21).  The call exposes the state after n_steps steps and the outputs of the LAST one
+ * (obs, reward, done, end effector), so on small shards (<= 262 144 envs) it runs FOUR steps per launch through the
+ * kernels of mt_rollout_fused -- joint angles, alive mask and return in registers, targets in LDS between them; every
+ * step still computes and writes its outputs -- bit-identical to the launch-per-step sequence, without three of four
+ * kernel boundaries and state re-fetches (MT_ROLLOUT_K=1 gives one launch per step back; then batches <= 131 072 envs are
+ * replayed from a HIP graph that the handle captures once per segment length).
  * On large batches (163 840 .. 3 M envs) the call runs as TWO independent chains of launches -- the two halves of the env
  * range (256-aligned) on two streams forked from the handle's stream: a step of env i depends only on env i, so the
  * results are bit-identical, and one half's kernel boundary is hidden behind the other half's kernel (-10 % per step at
@@ -286,6 +300,13 @@ MT_API int mt_reduce_returns(mt_handle h, int field, int row, mt_return_stats* o
 /* HIP-event timer on the handle's stream (wall-clock of test_multi.py:16-18, device side). */
 MT_API int mt_timer_start(mt_handle h);
 MT_API int mt_timer_stop(mt_handle h, float* elapsed_ms);
+/* The same end mark WITHOUT joining the chains and without a host wait: one end event on every stream of the handle
+ * that may still carry work (its stream, the chain streams while forked); mt_timer_read waits for them and returns the
+ * time from mt_timer_start to the LAST of them -- and to the end of an exchange begun with mt_gather_returns_begin that
+ * was still pending at the mark.  bench.py brackets each timed region with the pair to report the region's device
+ * timeline next to its wall clock. */
+MT_API int mt_timer_stop_async(mt_handle h);
+MT_API int mt_timer_read(mt_handle h, float* elapsed_ms);
 /* Lap timer: any number of begin/end event pairs recorded on the stream WITHOUT host synchronisation;
  * mt_timer_laps_total synchronises once, returns the summed device time of all laps and clears them.  Lets a
  * benchmark time only its step launches inside a longer region without stalling the GPU at every lap. */
@@ -309,6 +330,13 @@ MT_API int mt_fk_batch(int device, const float* dh_table, int dof, int mode, con
 MT_API int mt_route_trace(int device, const float* dh_table, int dof, int substeps, const float* prev,
                           const float* action, int64_t n, float* out);
 MT_API int mt_r_theta_batch(int device, const float* v1, const float* v2, int64_t n, float* out_r_theta);
+/* Measurement aid ("report against the measured bandwidth"): a streaming kernel with exactly the memory
+ * operations of one mt_step_random -- dof + 3 targets + 2 rows read, dof + 2 rewritten in place, 3 targets + 4 rows and
+ * one byte row written non-temporally, one env per lane, the arena's row pitch -- and none of its arithmetic, run `reps`
+ * times over n_envs envs.  us_per_pass = average device time of a pass, bytes_per_pass = (8 dof + 24 targets + 33) x
+ * n_envs.  Built for (dof, targets) = (4, 7), (7, 7), (4, 10); allocates and frees its own buffers. */
+MT_API int mt_stream_probe(int device, int dof, int n_targets, int64_t n_envs, int reps, float* us_per_pass,
+                           int64_t* bytes_per_pass);
 
 #ifdef __cplusplus
 }

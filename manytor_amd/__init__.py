@@ -6,7 +6,7 @@ HIP launch.  See DESIGN.md / INTEGRATION.md.
 """
 from ._lib import ManytorError, device_count  # noqa: F401
 from .api import (DEVICE_ACTIONS, HOST, PORT, BatchView, Environment, Multienv, dh, fk, r_theta)  # noqa: F401
-from .engine import (DH7_TABLE, REF_DH_TABLE, StepEngine, comm_unique_id, fk_batch, r_theta_batch,  # noqa: F401
+from .engine import (DH7_TABLE, REF_DH_TABLE, StepEngine, comm_unique_id, fk_batch, r_theta_batch, stream_probe,  # noqa: F401
                      route_trace)
 from .viewer import ViewerLink  # noqa: F401
 from . import _lib as lib  # noqa: F401

@@ -88,6 +88,7 @@ PROTOTYPES = {
     "mt_create": (C.c_int, [C.POINTER(_HANDLE), C.POINTER(MtConfig)]),
     "mt_destroy": (C.c_int, [_HANDLE]),
     "mt_step_kernel_name": (C.c_char_p, [_HANDLE]),
+    "mt_describe_dispatch": (C.c_char_p, [_HANDLE]),
     "mt_set_stream": (C.c_int, [_HANDLE, C.c_void_p]),
     "mt_use_own_stream": (C.c_int, [_HANDLE]),
     "mt_sync": (C.c_int, [_HANDLE]),
@@ -122,6 +123,8 @@ PROTOTYPES = {
     "mt_reduce_returns": (C.c_int, [_HANDLE, C.c_int, C.c_int, C.c_void_p]),
     "mt_timer_start": (C.c_int, [_HANDLE]),
     "mt_timer_stop": (C.c_int, [_HANDLE, C.POINTER(C.c_float)]),
+    "mt_timer_stop_async": (C.c_int, [_HANDLE]),
+    "mt_timer_read": (C.c_int, [_HANDLE, C.POINTER(C.c_float)]),
     "mt_timer_lap_begin": (C.c_int, [_HANDLE]),
     "mt_timer_lap_end": (C.c_int, [_HANDLE]),
     "mt_timer_laps_total": (C.c_int, [_HANDLE, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
@@ -129,6 +132,7 @@ PROTOTYPES = {
     "mt_fk_batch": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_void_p]),
     "mt_route_trace": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "mt_r_theta_batch": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "mt_stream_probe": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int64)]),
 }
 
 _lib = None

@@ -102,23 +102,75 @@ int match_static(const DhConst& t, int dof) {
   return 0;
 }
 
-// whole_rows: the launch covers the batch or a 256-aligned range of it (not the single-env view), so threads past the
-// end of the range may read on to the end of their block inside the rows (what the TT kernels do before their barrier)
-// Blocks per CU for a chain launch of the sampled-action prefetch kernel of a compile-time table (PF + TT, 74-76 VGPRs: six
-// blocks fit).  Between ~300 k and ~1.3 M arms in the batch the chains run faster with fewer resident blocks than the
-// registers allow -- fewer rows in flight per memory channel, and the chains' kernels take turns instead of running their
-// load and store phases side by side.  The best cap follows the TOTAL batch, whatever the number of chains
-// (tools/ab_blocks_per_cu.sh, profiles/r03_variants.md section 12; us per step, no cap -> best cap):
-//   327 680 arms 12.3 -> 11.6 (3 blocks)    393 216: 14.4 -> 13.3 (3)     524 288: 19.1 -> 18.0 (4)     655 360: 22.9 -> 22.1 (4)
-//   786 432: 27.4 -> 26.1 (4)     1 048 576: 35.2 -> 34.5 (5)     >= 1 179 648 and <= 262 144: nothing
-// Keyed here by the envs of the launch with the default two chains in mind (half the batch).  Chain launches only.  The
-// cap is applied at launch time the usual way, with dynamic LDS nobody touches: a block then claims 1 / cap of the CU's
-// 160 KB.  MT_BLOCKS_PER_CU overrides (0 = none).
+// ---- the dispatch policy: ONE table of every size threshold the host picks a schedule by ------------------------------
+// Every schedule of a kernel gives the same bits (tests/test_gpu_parity.py: test_step_kernel_variants_are_bit_identical,
+// test_rollout_in_independent_chains_equals_plain_launches, ...), so this table is about time only.  The numbers come from
+// the sweeps named beside them (tools/variant_sweep.py, size_sweep.py, chain_sweep.py, fused_split_sweep.py,
+// ab_blocks_per_cu.sh; profiles/r02_variants.md, r03_variants.md, r04_variants.md).  choose_dispatch() below is the only
+// reader; the MT_* environment variables override single entries for experiments and tests, and mt_describe_dispatch()
+// reports the table, the overrides and what was resolved for a handle.
+struct BlockCap {
+  int64_t from, below;  // envs of the launch
+  int blocks;           // resident blocks per CU
+};
+struct DispatchPolicy {
+  // step_split_kernel: one env over 4 / 2 lanes while the batch is so small that a launch is one wave's dependent chain
+  //   <= 49 152 arms: 4.5-5.5 us per step against 5.3-5.9 with prefetch (49 152: 5.47 against 5.70 with 2 lanes);
+  //   <= 65 536: 5.8 against 6.0 (4 lanes: 6.3)                                  [profiles/r03_variant_sweep_final.json]
+  int64_t step_split4_max = 49152, step_split2_max = 65536;
+  // prefetch (PF = 8) for arms other than the reference arm: up to here (long arms lose more to the lower occupancy than
+  // they gain); the reference arm takes it at every size (7.1 against 7.8 us at 131 072, 19.9 against 21.0 at 524 288)
+  int64_t prefetch_other_max = 131072;
+  // rollout_split_kernel (fused rollout): 4 lanes per env up to 32 768 arms, 2 up to 131 072 (3.60 against 4.50 us per step
+  // at 98 304 arms, 4.37 against 4.50 at 131 072; one env per lane wins from 196 608 on)   [r03_fused_split_sweep.json]
+  int64_t fused_split4_max = 32768, fused_split2_max = 131072;
+  // reset_split_kernel: the target draw over 4 lanes per env (11.2 -> 6.9 us at 16 384 arms, 12.1 -> 10.0 at 65 536, a tie
+  // at 131 072, slower above)
+  int64_t reset_split_max = 65536;
+  // mt_rollout replays a cached HIP graph of its launches up to here (-3..6 % per step; nothing above, where the kernels
+  // are the time)                                                                        [r02_graph_replay.json]
+  int64_t graph_max = 131072;
+  // mt_rollout / mt_step as two chains of launches on two streams (us per step incl. the per-episode reset, one chain ->
+  // two: 163 840 envs 8.45 -> 7.15, 262 144: 10.5 -> 8.7, 524 288: 21.5 -> 19.8, 1 M: 39.9 -> 36.3, 2 M: 74.6 -> 69.0;
+  // nothing at 4 M; at 98 304-131 072 two chains win back to back but lose from an idle device)     [r03_variants.md 2]
+  int64_t chains_min = 163840, chains_max = 3145728;
+  // a chain is a batch of span envs, but two kernels are in flight, so the lane-split schedules stop paying earlier
+  // (2 x 65 536 envs: 6.85 us with one env per lane against 7.0-7.35 with two lanes; 2 x 49 152: 6.8 with two against 6.95)
+  int64_t chain_split4_max = 16384, chain_split2_max = 49152, chain_prefetch_other_max = 131072;
+  // launches of the prefetch kernel over at least this many envs take LaneOffset<false> (kernels.h FLAT: the HBM-bound
+  // regime, 0.7-2.4 % faster there)                                                      [r03_ab_flat_from.txt]
+  int64_t flat_from = 393216;
+  // resident blocks per CU of a CHAIN launch of the sampled-action PF + TT kernel (74-76 VGPRs: six fit), keyed by the
+  // envs of the launch with two chains in mind (us per step of the batch, no cap -> cap: 327 680 arms 12.3 -> 11.6 (3),
+  // 393 216: 14.4 -> 13.3 (3), 524 288: 19.1 -> 18.0 (4), 786 432: 27.4 -> 26.1 (4), 1 048 576: 35.2 -> 34.5 (5); nothing
+  // at >= 1 179 648 and <= 262 144 arms)                                                 [r03_variants.md 12]
+  BlockCap block_caps[3] = {{147456, 229376, 3}, {229376, 458752, 4}, {458752, 589824, 5}};
+  // mt_rollout(T) exposes the state after T steps and the outputs of the last one, so on small shards -- where a launch
+  // per step is a kernel boundary plus a re-fetch of the whole state past L2 for 4-6 us of work -- it runs
+  // `multi_step_k` steps per launch through the rollout kernels (state in registers / LDS between them; every step
+  // still writes its obs / reward / done / ee), bit-identical by construction             [r04_variants.md 1]
+  int64_t multi_step_max = 262144;
+  int multi_step_k = 4;
+  // the angle-addition recurrence is run (S - 1) / 2 rotations from each end of a route; beyond this many the per-pose
+  // polynomial sincos kernels take over (drift: 12 rotations 3.3e-5 / 6.6e-5 in z on the 4- / 7-joint arm, 31 rotations
+  // 8.6e-5 / 1.3e-4, outside the 1e-4 position tolerance)                                [tests/test_gpu_zmin.py]
+  int max_recurrence_rotations = 12;
+  // rows of more than this many envs get a 1 KiB pad (rows an exact power of two apart alias onto the same channels)
+  int64_t ld_pad_above = 16384;
+  int ld_pad_floats = 256;
+};
+static const DispatchPolicy kPolicy{};
+
+// Blocks per CU for a chain launch of the sampled-action prefetch kernel of a compile-time table.  The cap is applied at
+// launch time the usual way, with dynamic LDS nobody touches: a block then claims 1 / cap of the CU's 160 KB.
+// MT_BLOCKS_PER_CU overrides (0 = none; 1 and 2 cannot be realised inside the default 64 KB dynamic-LDS limit and are
+// raised to 3).
 static int step_blocks_per_cu(mt_handle h, int64_t n_launch) {
   if (h->blocks_per_cu_override >= 0) return h->blocks_per_cu_override;
-  if (n_launch >= h->n) return 0;
-  if (n_launch < 147456 || n_launch >= 589824) return 0;  // (1 179 648 arms: a tie; 294 912: -2 % with 3: r03_ab_blocks_edges.txt)
-  return n_launch < 229376 ? 3 : (n_launch < 458752 ? 4 : 5);
+  if (n_launch >= h->n) return 0;  // chain launches only
+  for (const BlockCap& c : kPolicy.block_caps)
+    if (n_launch >= c.from && n_launch < c.below) return c.blocks;
+  return 0;
 }
 static size_t lds_pad_for_blocks(int blocks_per_cu, size_t static_lds) {
   if (blocks_per_cu <= 0) return 0;
@@ -126,6 +178,137 @@ static size_t lds_pad_for_blocks(int blocks_per_cu, size_t static_lds) {
   return per_block > static_lds ? std::min<size_t>(per_block, 65536) - static_lds : 0;  // <= 64 KB in all: no attribute needed
 }
 
+// Envs per chain: equal shares rounded up to whole 256-env blocks; the last chain takes what is left (possibly less).
+int64_t chain_span(mt_handle h, int chains) {
+  const int64_t per = (h->n + chains - 1) / chains;
+  return (per + 255) / 256 * 256;
+}
+
+static bool env_int(const char* name, long long* v) {  // set AND non-empty (atoi("") would read as 0)
+  const char* e = std::getenv(name);
+  if (!e || !*e) return false;
+  *v = std::atoll(e);
+  return true;
+}
+
+// Every schedule choice of a handle, from kPolicy, the handle's size / table / flags (h->cfg, h->args.dh must be set) and
+// the MT_* overrides.  Called once by mt_create.  The overrides that were seen are kept in h->overrides for
+// mt_describe_dispatch.
+static void choose_dispatch(mt_handle h) {
+  const mt_config* cfg = &h->cfg;
+  const DispatchPolicy& P = kPolicy;
+  const int64_t n = cfg->n_envs;
+  long long v = 0;
+  h->overrides.clear();
+  auto seen = [&](const char* name) { h->overrides += (h->overrides.empty() ? "" : ",") + std::string(name) + "=" + std::getenv(name); };
+
+  h->trig = (cfg->flags & MT_FLAG_HW_TRIG) ? 2 : ((cfg->flags & MT_FLAG_DIRECT_TRIG) ? 1 : 0);
+  if (cfg->flags & MT_FLAG_ABLATE_LOOP) h->trig = (cfg->flags & MT_FLAG_ABLATE_OBS) ? 4 : 3;
+  else if (cfg->flags & MT_FLAG_ABLATE_OBS) h->trig = 5;   /* OBS alone = arithmetic-only build */
+  // Routes with more rotations per half than the recurrence tolerates take the per-pose polynomial sincos (the
+  // MT_FLAG_DIRECT_TRIG kernels: no drift, about twice the arithmetic).
+  const bool long_route = h->trig == 0 && (cfg->substeps - 1) / 2 > P.max_recurrence_rotations;
+  if (long_route) h->trig = 1;
+  h->lds_table = (cfg->flags & MT_FLAG_DH_IN_LDS) != 0 && !long_route;  // the LDS-table variant exists for the recurrence only
+  // other rows than the reference's last two: the runtime-table kernel with runtime frames (RtTableF), one env per lane
+  h->custom_frames = !(h->args.dh.fo == h->D - 2 && h->args.dh.fe == h->D - 1);
+  h->static_kind = ((cfg->flags & (MT_FLAG_NO_SPECIALIZE | MT_FLAG_DH_IN_LDS)) || h->custom_frames) ? 0 : match_static(h->args.dh, h->D);
+
+  // ---- one launch per step: which step kernel for which batch (all variants give the same bits) ----
+  h->split = n <= P.step_split4_max ? 4 : (n <= P.step_split2_max ? 2 : 0);
+  h->prefetch = h->static_kind == 1 || n <= P.prefetch_other_max;
+  h->rollout_split = n <= P.fused_split4_max ? 4 : (n <= P.fused_split2_max ? 2 : 0);
+  bool split_forced = false;
+  if (env_int("MT_SPLIT", &v)) {
+    h->split = (v == 2 || v == 4) ? (int)v : 0;
+    h->rollout_split = h->split;
+    split_forced = true;
+    seen("MT_SPLIT");
+  }
+  h->prefetch_forced = false;
+  if (env_int("MT_PREFETCH", &v)) {
+    h->prefetch = v != 0;
+    h->prefetch_forced = true;
+    seen("MT_PREFETCH");
+  }
+  h->reset_split = n <= P.reset_split_max;
+  if (env_int("MT_RESET_SPLIT", &v)) {
+    h->reset_split = v != 0;
+    seen("MT_RESET_SPLIT");
+  }
+  h->graph_mode = -1;
+  h->graph_max = P.graph_max;
+  if (env_int("MT_GRAPH", &v)) {
+    h->graph_mode = v != 0 ? 1 : 0;
+    seen("MT_GRAPH");
+  }
+  h->flat_from = P.flat_from;
+  if (env_int("MT_FLAT_FROM", &v)) {
+    h->flat_from = std::max<long long>(0, v);
+    seen("MT_FLAT_FROM");
+  }
+  h->blocks_per_cu_override = -1;
+  if (env_int("MT_BLOCKS_PER_CU", &v)) {
+    // 1 and 2 blocks per CU would need more than the default 64 KB of dynamic LDS per block: the smallest cap the pad can
+    // realise is 3, and the kernel-name string reports what is really applied
+    const int c = (int)std::max<long long>(0, std::min<long long>(8, v));
+    h->blocks_per_cu_override = (c == 1 || c == 2) ? 3 : c;
+    seen("MT_BLOCKS_PER_CU");
+  }
+  // End-pose sines / cosines from the whole-degree table (step kernels with TT; profiles/r03_variants.md section 3)
+  h->trig_steps = h->static_kind != 0;
+  if (env_int("MT_TRIG_TABLE", &v)) {
+    h->trig_steps = v != 0 && h->static_kind != 0;
+    seen("MT_TRIG_TABLE");
+  }
+
+  // ---- mt_rollout / mt_step as independent chains of launches on separate streams (engine_internal.h) ----
+  h->chains = (n >= P.chains_min && n <= P.chains_max) ? 2 : 1;
+  if (env_int("MT_CHAINS", &v)) {
+    h->chains = (int)std::max<long long>(1, std::min<long long>(mt_engine::kMaxChains, v));
+    seen("MT_CHAINS");
+  }
+  if (n < 2 * 256) h->chains = 1;
+  h->lazy_chains = true;
+  if (env_int("MT_LAZY_CHAINS", &v)) {  // 0: join at the end of every call
+    h->lazy_chains = v != 0;
+    seen("MT_LAZY_CHAINS");
+  }
+
+  // ---- mt_rollout: several steps per launch on small shards (the rollout kernels; default trigonometry only) ----
+  h->multi_k = (n <= P.multi_step_max) ? P.multi_step_k : 1;
+  if (env_int("MT_ROLLOUT_K", &v)) {
+    h->multi_k = (int)std::max<long long>(1, std::min<long long>(64, v));
+    seen("MT_ROLLOUT_K");
+  }
+
+  if (h->custom_frames) {
+    h->lds_table = false;
+    h->split = 0;
+    h->rollout_split = 0;
+    h->prefetch = false;
+  }
+  // A chain of a multi-chain call is a batch of chain_span() envs: its launches use the schedule for THAT size
+  h->chain_split = h->split;
+  h->chain_prefetch = h->prefetch;
+  h->chain_rollout_split = h->rollout_split;
+  if (h->chains > 1) {
+    const int64_t span = chain_span(h, h->chains);
+    h->chain_split = span <= P.chain_split4_max ? 4 : (span <= P.chain_split2_max ? 2 : 0);
+    h->chain_prefetch = h->static_kind == 1 || span <= P.chain_prefetch_other_max;
+    h->chain_rollout_split = span <= P.fused_split4_max ? 4 : (span <= P.fused_split2_max ? 2 : 0);
+    if (split_forced) h->chain_split = h->chain_rollout_split = h->split;
+    if (h->prefetch_forced) h->chain_prefetch = h->prefetch;
+    if (h->custom_frames) {
+      h->chain_split = 0;
+      h->chain_rollout_split = 0;
+      h->chain_prefetch = false;
+    }
+  }
+}
+
+// whole_rows: the launch covers the batch or a 256-aligned range of it (not the single-env view), so threads past the
+// end of the range may read on to the end of their block inside the rows (what the TT kernels do before their barrier)
 template <class Tbl, bool LDS_OK>
 void launch_step_t(mt_handle h, const StepArgs& args, bool sample, bool whole_rows) {
   const dim3 g = grid_for(args.n), b(kBlock);
@@ -261,12 +444,6 @@ void launch_step(mt_handle h, bool sample) { launch_step(h, h->args, h->trace, s
 // ---- multi-chain rollouts ------------------------------------------------------------------------------------------
 StepArgs args_for_range(mt_handle h, const StepArgs& base, int64_t off, int64_t cnt);
 int check_launch(mt_handle h, const char* what);
-// Envs per chain: equal shares rounded up to whole 256-env blocks; the last chain takes what is left (possibly less).
-int64_t chain_span(mt_handle h, int chains) {
-  const int64_t per = (h->n + chains - 1) / chains;
-  return (per + 255) / 256 * 256;
-}
-
 int ensure_chains(mt_handle h, int chains) {
   if (!h->ev_fork) MT_HIP(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
   for (int c = 1; c < chains; ++c) {
@@ -276,10 +453,10 @@ int ensure_chains(mt_handle h, int chains) {
   return MT_OK;
 }
 
-// One chain's T sampled steps on the handle's CURRENT stream (h->stream): chain c owns envs [c * span, (c + 1) * span).  The
+// One chain's T steps on the handle's CURRENT stream (h->stream): chain c owns envs [c * span, (c + 1) * span).  The
 // step-kernel schedule is the one for the chain's env count (a chain is a batch of `span` envs).  `a0` carries seed /
-// major_base; step s is launched with major = major0 + s.
-void launch_chain(mt_handle h, const StepArgs& a0, uint32_t major0, int T, int chains, int c) {
+// major_base; step s is launched with major = major0 + s.  sample = false: staged actions (mt_step), T = 1.
+void launch_chain(mt_handle h, const StepArgs& a0, uint32_t major0, int T, int chains, int c, bool sample = true) {
   const int64_t span = chain_span(h, chains), off = (int64_t)c * span;
   if (off >= h->n) return;
   StepArgs as = args_for_range(h, a0, off, std::min(span, h->n - off));
@@ -289,7 +466,7 @@ void launch_chain(mt_handle h, const StepArgs& a0, uint32_t major0, int T, int c
   h->prefetch = h->chain_prefetch;
   for (int s = 0; s < T; ++s) {
     as.major = major0 + (uint32_t)s;
-    launch_step(h, as, nullptr, true, true);
+    launch_step(h, as, nullptr, sample, true);
   }
   h->split = keep_split;
   h->prefetch = keep_pf;
@@ -403,28 +580,46 @@ void launch_joints_d(mt_handle h, float* out) {
   hipLaunchKernelGGL((joints_kernel<D>), grid_for(h->n), dim3(kBlock), 0, h->stream, h->args, out);
 }
 
+// The rollout kernels on the envs `a` describes (the whole batch or a chain's 256-aligned range), `split` lanes per env.
 template <class Tbl, int L>
-void launch_rollout_split_t(mt_handle h, const RolloutArgs& r) {
+void launch_rollout_split_t(mt_handle h, const StepArgs& a, const RolloutArgs& r) {
   const int64_t per_block = kBlock / L;
   const size_t lds = (size_t)3 * h->K * per_block * sizeof(float) + (ActionTrigTable<Tbl>::value ? kTrigEntries * sizeof(SinCos) : 0);
   if (lds > 65536)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_split_kernel<Tbl, L>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((rollout_split_kernel<Tbl, L>), dim3((unsigned)((h->n + per_block - 1) / per_block)), dim3(kBlock), lds,
-                     h->stream, h->args, r);
+  hipLaunchKernelGGL((rollout_split_kernel<Tbl, L>), dim3((unsigned)((a.n + per_block - 1) / per_block)), dim3(kBlock), lds,
+                     h->stream, a, r);
 }
 
 template <class Tbl>
-void launch_rollout_t(mt_handle h, const RolloutArgs& r) {
-  if (h->rollout_split == 4) return launch_rollout_split_t<Tbl, 4>(h, r);
-  if (h->rollout_split == 2) return launch_rollout_split_t<Tbl, 2>(h, r);
+void launch_rollout_t(mt_handle h, const StepArgs& a, int split, const RolloutArgs& r) {
+  if (split == 4) return launch_rollout_split_t<Tbl, 4>(h, a, r);
+  if (split == 2) return launch_rollout_split_t<Tbl, 2>(h, a, r);
   // 21.5 KB at K = 7, 96 KB at K = 32 (of 160 KB), + 3.6 KB for the action sin / cos table of the compile-time tables
   const size_t lds = (size_t)3 * h->K * kBlock * sizeof(float) + (ActionTrigTable<Tbl>::value ? kTrigEntries * sizeof(SinCos) : 0);
   if (lds > 65536)  // above the default dynamic-LDS limit the kernel has to be told
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_kernel<Tbl>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((rollout_kernel<Tbl>), grid_for(h->n), dim3(kBlock), lds, h->stream, h->args, r);
+  hipLaunchKernelGGL((rollout_kernel<Tbl>), grid_for(a.n), dim3(kBlock), lds, h->stream, a, r);
 }
+
+void launch_rollout(mt_handle h, const StepArgs& a, int split, const RolloutArgs& r) {
+  if (h->static_kind == 1) return launch_rollout_t<Ref4Table>(h, a, split, r);
+  if (h->static_kind == 2) return launch_rollout_t<Dh7Table>(h, a, split, r);
+  switch (h->D) {
+    case 2: launch_rollout_t<RtTable<2>>(h, a, split, r); break;
+    case 3: launch_rollout_t<RtTable<3>>(h, a, split, r); break;
+    case 4: launch_rollout_t<RtTable<4>>(h, a, split, r); break;
+    case 5: launch_rollout_t<RtTable<5>>(h, a, split, r); break;
+    case 6: launch_rollout_t<RtTable<6>>(h, a, split, r); break;
+    case 7: launch_rollout_t<RtTable<7>>(h, a, split, r); break;
+    default: launch_rollout_t<RtTable<8>>(h, a, split, r); break;
+  }
+}
+
+// The rollout kernels implement the default trigonometry and the reference's frame rows only.
+bool fusable(mt_handle h) { return h->trig == 0 && !h->lds_table && !h->trace && !h->custom_frames; }
 
 int check_launch(mt_handle h, const char* what) {
   hipError_t e = hipGetLastError();
@@ -487,6 +682,37 @@ static int64_t first_unusable(const float* v, int64_t count, uint32_t limit) {
 static int order_behind_inplace_gather(mt_handle h, hipStream_t stream) {
   if (h->gather_pending && h->gather_inplace) MT_HIP(h, hipStreamWaitEvent(stream, h->ev_g1, 0));
   return MT_OK;
+}
+
+// Chains a whole-batch call may run as, right now: the handle's chain count unless the sub-step trace is on or the caller
+// is capturing the handle's stream into a graph of their own (they get the plain single-stream sequence).
+static int usable_chains(mt_handle h) {
+  if (h->chains <= 1 || h->trace) return 1;
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(h->stream, &st) != hipSuccess || st != hipStreamCaptureStatusNone) {
+    (void)hipGetLastError();
+    return 1;
+  }
+  return h->chains;
+}
+
+// fn(c, off, cnt) once per chain with h->stream switched to the chain's stream; forks first, settles afterwards.
+template <class F>
+static int per_chain(mt_handle h, int chains, const char* what, F&& fn) {
+  int rc = fork_chains(h, chains);
+  if (rc) return rc;
+  const int64_t span = chain_span(h, chains);
+  hipStream_t root = h->stream;
+  for (int c = 0; c < chains; ++c) {
+    const int64_t off = (int64_t)c * span;
+    if (off >= h->n) continue;
+    h->stream = c == 0 ? root : h->chain_streams[c];
+    fn(c, off, std::min(span, h->n - off));
+  }
+  h->stream = root;
+  rc = check_launch(h, what);
+  if (rc) return rc;
+  return settle_chains(h);
 }
 
 constexpr uint32_t kMaxAngleBits = 0x47000000u;   // 32768.0f: the bound of unusable_angle (kernels.h)
@@ -555,69 +781,11 @@ int mt_create(mt_handle* out, const mt_config* cfg) {
   // (256 floats): round 1 used 4 KiB, which is fine at 1 M arms but pathological at 262 144 (row stride 1 MiB + 4 KiB:
   // 14.7 us per step against 11.7 with 1 KiB; tools/pad_sweep.py, profiles/r02_variants.md section 6); 1 KiB is within
   // 1 % of the best pad at every size tried.  MT_LD_PAD (floats) overrides it for experiments.
-  int64_t pad = (cfg->n_envs > 16384) ? 256 : 0;
+  int64_t pad = (cfg->n_envs > kPolicy.ld_pad_above) ? kPolicy.ld_pad_floats : 0;
   if (const char* env = std::getenv("MT_LD_PAD")) pad = (int64_t)align_up((size_t)std::atoll(env), 64);
   h->ld += pad;
   h->D = cfg->dof;
   h->K = cfg->n_targets;
-  h->trig = (cfg->flags & MT_FLAG_HW_TRIG) ? 2 : ((cfg->flags & MT_FLAG_DIRECT_TRIG) ? 1 : 0);
-  if (cfg->flags & MT_FLAG_ABLATE_LOOP) h->trig = (cfg->flags & MT_FLAG_ABLATE_OBS) ? 4 : 3;
-  else if (cfg->flags & MT_FLAG_ABLATE_OBS) h->trig = 5;   /* OBS alone = arithmetic-only build */
-  // The angle-addition recurrence of the interior sub-steps is run from both ends of the route, (S - 1) / 2 rotations
-  // per half.  Its drift grows with the number of rotations: measured against the fp64 oracle over 2 x 1 048 576
-  // routes per case (tests/test_gpu_zmin.py), 12 rotations (S = 25, the reference's literal, manytor.py:178) cost
-  // 3.3e-5 in z on the reference arm and 6.6e-5 on the 7-joint arm, 31 rotations (S = 64) 8.6e-5 / 1.3e-4 -- outside the
-  // 1e-4 position tolerance.  Longer routes therefore take the per-pose polynomial sincos (the MT_FLAG_DIRECT_TRIG
-  // kernels: no drift, about twice the arithmetic) instead of the recurrence.
-  constexpr int kMaxRecurrenceRotations = 12;
-  const bool long_route = h->trig == 0 && (cfg->substeps - 1) / 2 > kMaxRecurrenceRotations;
-  if (long_route) h->trig = 1;
-  h->lds_table = (cfg->flags & MT_FLAG_DH_IN_LDS) != 0 && !long_route;  // the LDS-table variant exists for the recurrence only
-  // Which step kernel for which batch (tools/variant_sweep.py, profiles/r02_variants.md section 3; all variants give
-  // the same bits):
-  //   <= 49 152 arms   one env over 4 lanes   (4.5-5.5 us per step against 5.3-5.9 with prefetch; at 49 152: 5.47 against
-  //                    5.70 with 2 lanes -- profiles/r03_variant_sweep_final.json)
-  //   <= 65 536        one env over 2 lanes   (5.8 against 6.0; 4 lanes: 6.3)
-  //   above            one env per lane, with the targets prefetched into registers (PF) for the reference arm at every
-  //                    size (7.1 against 7.8 us at 131 072 arms, 19.9 against 21.0 at 524 288, 39.4 against 39.5 at 1 M)
-  //                    and for other arms up to 131 072 arms (long arms lose more to the lower occupancy than they gain)
-  // MT_SPLIT = 0/2/4 and MT_PREFETCH = 0/1 override the choice for experiments and tests.
-  h->split = cfg->n_envs <= 49152 ? 4 : (cfg->n_envs <= 65536 ? 2 : 0);
-  h->prefetch = cfg->n_envs <= 131072;  // widened for the reference arm once the table is known (below)
-  // The fused rollout keeps two lanes per env up to 131 072 arms (tools/fused_split_sweep.py, round 3: 3.60 against 4.50 us
-  // per step at 98 304 arms, 4.37 against 4.50 at 131 072; one env per lane wins from 196 608 on).
-  h->rollout_split = cfg->n_envs <= 32768 ? 4 : (cfg->n_envs <= 131072 ? 2 : 0);
-  if (const char* env = std::getenv("MT_SPLIT")) {
-    const int v = std::atoi(env);
-    h->split = (v == 2 || v == 4) ? v : 0;
-    h->rollout_split = h->split;
-  }
-  // The reset's target draw is spread over 4 lanes per env while the batch is small enough for the kernel to be one
-  // wave per SIMD walking its Philox blocks serially: 11.2 -> 6.9 us at 16 384 arms, 12.1 -> 10.0 at 65 536, a tie at
-  // 131 072, slower above (same bits; MT_RESET_SPLIT = 0/1 overrides).
-  h->reset_split = cfg->n_envs <= 65536;
-  if (const char* env = std::getenv("MT_RESET_SPLIT")) h->reset_split = std::atoi(env) != 0;
-  if (const char* env = std::getenv("MT_GRAPH")) h->graph_mode = std::atoi(env) != 0 ? 1 : 0;
-  // mt_rollout as independent chains of launches on separate streams (engine_internal.h): MT_CHAINS = 1..4 overrides
-  // Two chains from 163 840 to 3 M envs (tools/chain_sweep.py --steady, tools/chain_variant_probe.py, tools/size_sweep.py,
-  // profiles/r03_variants.md section 2; us per step incl. the per-episode reset, one chain -> two): 163 840 envs 8.45 -> 7.15,
-  // 262 144 envs 10.5 -> 8.7, 524 288 envs 21.5 -> 19.8, 1 M envs 39.9 -> 36.3, 2 M envs 74.6 -> 69.0; nothing at 4 M, where
-  // the launches are long and purely HBM-bound.  At 98 304 .. 131 072 envs two chains (with one cached graph per chain) win
-  // in a long back-to-back run (98 304: 7.1 -> 6.1 us per step, 131 072: 7.14 -> 6.98) but lose when a segment starts on an
-  // idle device (131 072: 7.0 -> 7.4-8.1 us per step over a 50-step segment: two graph launches and a fork against one
-  // graph launch): one chain and its cached graph stay the choice there.
-  h->chains = (cfg->n_envs >= 163840 && cfg->n_envs <= 3145728) ? 2 : 1;
-  if (const char* env = std::getenv("MT_CHAINS")) h->chains = std::max(1, std::min((int)mt_engine::kMaxChains, std::atoi(env)));
-  if (cfg->n_envs < 2 * 256) h->chains = 1;
-  if (const char* env = std::getenv("MT_LAZY_CHAINS")) h->lazy_chains = std::atoi(env) != 0;  // 0: join at the end of every call
-  if (const char* env = std::getenv("MT_FLAT_FROM"); env && *env) h->flat_from = std::max<long long>(0, std::atoll(env));
-  if (const char* env = std::getenv("MT_BLOCKS_PER_CU"); env && *env)  // (set but empty = not set: atoi("") would mean "no cap")
-    h->blocks_per_cu_override = std::max(0, std::min(8, std::atoi(env)));
-  h->prefetch_forced = false;
-  if (const char* env = std::getenv("MT_PREFETCH")) {
-    h->prefetch = std::atoi(env) != 0;
-    h->prefetch_forced = true;
-  }
 
   auto bail = [&](int code, const std::string& msg) {
     g_last_error = msg;
@@ -697,41 +865,7 @@ int mt_create(mt_handle* out, const mt_config* cfg) {
   a.dh.fo = (cfg->obs_frame + h->D) % h->D;
   a.dh.fe = (cfg->ee_frame + h->D) % h->D;
   // other rows than the reference's last two: the runtime-table kernel with runtime frames (RtTableF), one env per lane
-  h->custom_frames = !(a.dh.fo == h->D - 2 && a.dh.fe == h->D - 1);
-  if (h->custom_frames) {
-    h->lds_table = false;
-    h->split = 0;
-    h->rollout_split = 0;
-    h->prefetch = false;
-  }
-  h->static_kind = ((cfg->flags & (MT_FLAG_NO_SPECIALIZE | MT_FLAG_DH_IN_LDS)) || h->custom_frames) ? 0 : match_static(a.dh, h->D);
-  if (h->static_kind == 1 && !h->prefetch_forced) h->prefetch = true;
-  // End-pose sines / cosines from the whole-degree table (step kernels with TT; tools/variant_sweep.py,
-  // profiles/r03_variants.md): MT_TRIG_TABLE = 0/1 overrides.
-  h->trig_steps = h->static_kind != 0;
-  if (const char* env = std::getenv("MT_TRIG_TABLE")) h->trig_steps = std::atoi(env) != 0 && h->static_kind != 0;
-  // A chain of a multi-chain mt_rollout is a batch of chain_span() envs: its launches use the schedule for THAT size
-  // (same thresholds and overrides as the whole-batch choice above).
-  h->chain_split = h->split;
-  h->chain_prefetch = h->prefetch;
-  if (h->chains > 1) {
-    const int64_t span = chain_span(h, h->chains);
-    // (two kernels of `span` envs are in flight, so the chip is as full as under one launch of 2 x span: the lane-split
-    // schedules stop paying earlier than for a lone batch -- chain_variant_probe.py: 2 x 65 536 envs 6.85 us per step with one
-    // env per lane against 7.0-7.35 with two lanes, 2 x 49 152 envs 6.8 with two lanes against 6.95 with one)
-    h->chain_split = span <= 16384 ? 4 : (span <= 49152 ? 2 : 0);
-    h->chain_prefetch = span <= 131072;
-    if (const char* env = std::getenv("MT_SPLIT")) {
-      const int v = std::atoi(env);
-      h->chain_split = (v == 2 || v == 4) ? v : 0;
-    }
-    if (h->prefetch_forced) h->chain_prefetch = h->prefetch;
-    if (h->custom_frames) {
-      h->chain_split = 0;
-      h->chain_prefetch = false;
-    }
-    if (h->static_kind == 1 && !h->prefetch_forced) h->chain_prefetch = true;
-  }
+  choose_dispatch(h);
 #undef MT_HIP_C
   *out = h;
   return MT_OK;
@@ -752,6 +886,7 @@ int mt_destroy(mt_handle h) {
       (void)hipStreamDestroy(h->chain_streams[c]);
     }
     if (h->ev_join[c]) (void)hipEventDestroy(h->ev_join[c]);
+    if (h->ev1c[c]) (void)hipEventDestroy(h->ev1c[c]);
   }
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   if (h->graph_step0) (void)hipFree(h->graph_step0);
@@ -785,7 +920,55 @@ const char* mt_step_kernel_name(mt_handle h) {
                       ((h->trig == 0 && !h->lds_table && !h->chain_split && h->chain_prefetch && h->trig_steps &&
                         step_blocks_per_cu(h, chain_span(h, h->chains)) > 0)
                            ? ", " + std::to_string(step_blocks_per_cu(h, chain_span(h, h->chains))) + " blocks/CU" : std::string()) + "]";
+  if (h->multi_k > 1 && fusable(h)) {  // what mt_rollout launches on small shards instead of one step kernel per step
+    const int sp = h->chains > 1 ? h->chain_rollout_split : h->rollout_split;
+    h->kernel_name += " [mt_rollout: " + std::to_string(h->multi_k) + " steps per launch, " +
+                      (sp ? "rollout_split_kernel L=" + std::to_string(sp) : std::string("rollout_kernel")) + "]";
+  }
   return h->kernel_name.c_str();
+}
+
+const char* mt_describe_dispatch(mt_handle h) {
+  if (!h) return "";
+  const DispatchPolicy& P = kPolicy;
+  auto num = [](long long v) { return std::to_string(v); };
+  auto b = [](bool v) { return std::string(v ? "true" : "false"); };
+  const int64_t span = chain_span(h, h->chains);
+  const char* tbl = h->static_kind == 1 ? "Ref4Table" : (h->static_kind == 2 ? "Dh7Table" : nullptr);
+  const std::string table = tbl ? tbl : (h->custom_frames ? "RtTableF<" : "RtTable<") + std::to_string(h->D) + ">";
+  const bool rec = h->trig == 0 && !h->lds_table;   // the default recurrence kernels: the only ones with schedules
+  const bool multi = h->multi_k > 1 && fusable(h);
+  const bool graph = h->graph_mode > 0 || (h->graph_mode < 0 && h->n <= h->graph_max);
+  std::string caps = "[";
+  for (const BlockCap& c : P.block_caps) caps += std::string(caps.size() > 1 ? "," : "") + "[" + num(c.from) + "," + num(c.below) + "," + num(c.blocks) + "]";
+  caps += "]";
+  std::string& d = h->describe;
+  d = "{\"n_envs\":" + num(h->n) + ",\"ld\":" + num(h->ld) + ",\"dof\":" + num(h->D) + ",\"targets\":" + num(h->K) +
+      ",\"table\":\"" + table + "\",\"trig\":" + num(h->trig) + ",\"lds_table\":" + b(h->lds_table) + ",\"custom_frames\":" + b(h->custom_frames) +
+      // one launch per step: mt_step / mt_step_random on a one-chain handle
+      ",\"step\":{\"lanes_per_env\":" + num(rec && h->split ? h->split : 1) + ",\"prefetch\":" + b(rec && !h->split && h->prefetch) +
+      ",\"trig_table\":" + b(rec && h->trig_steps) + ",\"flat\":" + b(rec && !h->split && h->prefetch && h->n >= h->flat_from) + "}" +
+      // per-chain calls: mt_rollout, mt_step, mt_sample_actions, mt_set_actions(device), mt_reset_random
+      ",\"chains\":{\"count\":" + num(h->chains) + ",\"span\":" + num(h->chains > 1 ? span : h->n) + ",\"lazy\":" + b(h->lazy_chains) +
+      ",\"lanes_per_env\":" + num(rec && h->chain_split ? h->chain_split : 1) + ",\"prefetch\":" + b(rec && !h->chain_split && h->chain_prefetch) +
+      ",\"flat\":" + b(rec && !h->chain_split && h->chain_prefetch && span >= h->flat_from) +
+      ",\"blocks_per_cu\":" + num(h->chains > 1 && rec && !h->chain_split && h->chain_prefetch && h->trig_steps ? step_blocks_per_cu(h, span) : 0) + "}" +
+      ",\"rollout\":{\"form\":\"" + (multi ? "multi_step" : (h->chains > 1 ? "chained_steps" : (graph ? "graph_replay" : "launch_per_step"))) +
+      "\",\"steps_per_launch\":" + num(multi ? h->multi_k : 1) + ",\"graph\":" + b(!multi && graph) +
+      ",\"lanes_per_env\":" + num(std::max(1, multi ? (h->chains > 1 ? h->chain_rollout_split : h->rollout_split) : (rec ? (h->chains > 1 ? h->chain_split : h->split) : 0))) + "}" +
+      ",\"fused\":{\"usable\":" + b(fusable(h)) + ",\"lanes_per_env\":" + num(h->rollout_split ? h->rollout_split : 1) + "}" +
+      ",\"reset\":{\"lanes_per_env\":" + num(h->reset_split ? 4 : 1) + "}" +
+      ",\"overrides\":\"" + h->overrides + "\"" +
+      ",\"policy\":{\"step_split4_max\":" + num(P.step_split4_max) + ",\"step_split2_max\":" + num(P.step_split2_max) +
+      ",\"prefetch_other_max\":" + num(P.prefetch_other_max) + ",\"fused_split4_max\":" + num(P.fused_split4_max) +
+      ",\"fused_split2_max\":" + num(P.fused_split2_max) + ",\"reset_split_max\":" + num(P.reset_split_max) +
+      ",\"graph_max\":" + num(P.graph_max) + ",\"chains_min\":" + num(P.chains_min) + ",\"chains_max\":" + num(P.chains_max) +
+      ",\"chain_split4_max\":" + num(P.chain_split4_max) + ",\"chain_split2_max\":" + num(P.chain_split2_max) +
+      ",\"chain_prefetch_other_max\":" + num(P.chain_prefetch_other_max) + ",\"flat_from\":" + num(P.flat_from) +
+      ",\"block_caps\":" + caps + ",\"multi_step_max\":" + num(P.multi_step_max) + ",\"multi_step_k\":" + num(P.multi_step_k) +
+      ",\"max_recurrence_rotations\":" + num(P.max_recurrence_rotations) + ",\"ld_pad_above\":" + num(P.ld_pad_above) +
+      ",\"ld_pad_floats\":" + num(P.ld_pad_floats) + "}}";
+  return d.c_str();
 }
 
 int mt_set_stream(mt_handle h, void* hip_stream) {
@@ -919,8 +1102,44 @@ int mt_set_actions(mt_handle h, const void* actions, int dtype, int layout, int 
   MT_REQUIRE(h, actions != nullptr, "actions is NULL");
   MT_REQUIRE(h, layout == MT_ENV_MAJOR || layout == MT_SOA, "bad layout");
   MT_REQUIRE(h, dtype == MT_F32 || dtype == MT_F64 || dtype == MT_I32 || dtype == MT_I64, "bad action dtype");
-  MT_ENTER(h);
   const size_t es = (dtype == MT_F32 || dtype == MT_I32) ? 4 : 8;
+  // Device sources of a multi-chain handle are staged per chain -- each range's rows on its chain's stream, right ahead of
+  // that range's mt_step -- so that a policy loop (mt_set_actions(device) / mt_step, ...) keeps the chains forked.
+  const int chains = is_device ? usable_chains(h) : 1;
+  if (chains > 1) {
+    MT_ON_DEVICE(h, h->cfg.device);
+    const int D = h->D;
+    const int64_t ld = h->ld;
+    hipError_t copy_err = hipSuccess;
+    int rc = per_chain(h, chains, "set_actions (per chain)", [&](int, int64_t off, int64_t cnt) {
+      const dim3 g = grid_for(cnt), b(kBlock);
+      float* dst = h->args.actions + off;
+      if (layout == MT_SOA && dtype == MT_F32) {
+        hipError_t e = hipMemcpy2DAsync(dst, (size_t)ld * 4, (const float*)actions + off, (size_t)ld * 4, (size_t)cnt * 4, (size_t)D,
+                                        hipMemcpyDeviceToDevice, h->stream);
+        if (e != hipSuccess) copy_err = e;
+      } else if (layout == MT_ENV_MAJOR) {
+        const char* src = (const char*)actions + (size_t)off * D * es;
+        switch (dtype) {
+          case MT_F32: hipLaunchKernelGGL((env_major_to_soa<float>), g, b, 0, h->stream, (const float*)src, D, cnt, dst, ld); break;
+          case MT_F64: hipLaunchKernelGGL((env_major_to_soa<double>), g, b, 0, h->stream, (const double*)src, D, cnt, dst, ld); break;
+          case MT_I32: hipLaunchKernelGGL((env_major_to_soa<int32_t>), g, b, 0, h->stream, (const int32_t*)src, D, cnt, dst, ld); break;
+          default: hipLaunchKernelGGL((env_major_to_soa<int64_t>), g, b, 0, h->stream, (const int64_t*)src, D, cnt, dst, ld); break;
+        }
+      } else {
+        const char* src = (const char*)actions + (size_t)off * es;
+        switch (dtype) {
+          case MT_F64: hipLaunchKernelGGL((soa_to_soa_f32<double>), g, b, 0, h->stream, (const double*)src, D, cnt, ld, dst); break;
+          case MT_I32: hipLaunchKernelGGL((soa_to_soa_f32<int32_t>), g, b, 0, h->stream, (const int32_t*)src, D, cnt, ld, dst); break;
+          default: hipLaunchKernelGGL((soa_to_soa_f32<int64_t>), g, b, 0, h->stream, (const int64_t*)src, D, cnt, ld, dst); break;
+        }
+      }
+    });
+    if (rc) return rc;
+    if (copy_err != hipSuccess) return fail(h, MT_ERR_HIP, std::string("hipMemcpy2DAsync (actions): ") + hipGetErrorString(copy_err));
+    return MT_OK;
+  }
+  MT_ENTER(h);
   const int64_t cols = (layout == MT_SOA) ? h->ld : h->n;
   const size_t bytes = (size_t)h->D * cols * es;
   const void* src = actions;
@@ -959,6 +1178,14 @@ int mt_set_actions(mt_handle h, const void* actions, int dtype, int layout, int 
 
 int mt_sample_actions(mt_handle h, uint64_t seed, uint32_t step_idx) {
   MT_REQUIRE(nullptr, h != nullptr, "handle is NULL");
+  const int chains = usable_chains(h);
+  if (chains > 1) {  // per chain: each range's actions are written on its chain's stream, ahead of that range's mt_step
+    MT_ON_DEVICE(h, h->cfg.device);
+    return per_chain(h, chains, "sample_actions_kernel (per chain)", [&](int, int64_t off, int64_t cnt) {
+      hipLaunchKernelGGL(sample_actions_kernel, grid_for(cnt), dim3(kBlock), 0, h->stream, h->args.actions + off, cnt, h->ld, h->D,
+                         h->args.env_base + off, seed, step_idx);
+    });
+  }
   MT_ENTER(h);
   hipLaunchKernelGGL(sample_actions_kernel, grid_for(h->n), dim3(kBlock), 0, h->stream, h->args.actions, h->n, h->ld,
                      h->D, h->args.env_base, seed, step_idx);
@@ -969,6 +1196,18 @@ int mt_sample_actions(mt_handle h, uint64_t seed, uint32_t step_idx) {
 int mt_step(mt_handle h) {
   MT_REQUIRE(nullptr, h != nullptr, "handle is NULL");
   if (!h->is_reset) return fail(h, MT_ERR_STATE, "mt_step before mt_reset / mt_reset_random");
+  // The policy-in-the-loop step: on a multi-chain handle each half of the env range is one launch on its own stream, as in
+  // mt_rollout (a step of env i depends only on env i: same bits, one half's kernel boundary behind the other's kernel).
+  // On the handle's own stream the chains stay forked across mt_set_actions(device) / mt_sample_actions / mt_step calls;
+  // on a caller's stream (a torch policy on the same stream) every call forks behind the caller's work and joins back.
+  const int chains = usable_chains(h);
+  if (chains > 1) {
+    MT_ON_DEVICE(h, h->cfg.device);
+    const StepArgs a = h->args;
+    int rc = per_chain(h, chains, "step_kernel (per chain)", [&](int c, int64_t, int64_t) { launch_chain(h, a, a.major, 1, chains, c, false); });
+    h->args.flags &= ~kFlagWholeGoals;  // staged actions are anybody's floats
+    return rc;
+  }
   MT_ENTER(h);
   launch_step(h, false);
   h->args.flags &= ~kFlagWholeGoals;  // staged actions are anybody's floats
@@ -1109,7 +1348,7 @@ int mt_bad_action_count(mt_handle h, uint64_t* count) {
 // step index = its offset + a device word) and replayed -- 5-15 % less per step up to 131 072 arms, nothing above.
 static bool rollout_uses_graph(mt_handle h, int n_steps) {
   if (h->graph_mode == 0 || h->trace || n_steps < 4) return false;
-  if (h->graph_mode < 0 && h->n > 131072) return false;
+  if (h->graph_mode < 0 && h->n > h->graph_max) return false;
 
   hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(h->stream, &st) != hipSuccess || st != hipStreamCaptureStatusNone) {
@@ -1177,7 +1416,13 @@ static int rollout_graph(mt_handle h, int T, uint64_t seed, int chains, const mt
     }
   }
   if (h->graphs.size() >= 8) {  // a handful of segment lengths at most; drop the oldest beyond that
+    // its per-chain graphs may still be executing on the chain streams (lazily forked chains): fold them back and drain
+    // every stream a replay can be on before the executables go
+    int rcj = join_chains(h);
+    if (rcj) return rcj;
     MT_HIP(h, hipStreamSynchronize(h->stream));
+    for (int c = 1; c < mt_engine::kMaxChains; ++c)
+      if (h->chain_streams[c]) MT_HIP(h, hipStreamSynchronize(h->chain_streams[c]));
     for (hipGraphExec_t x : h->graphs.front().exec)
       if (x) (void)hipGraphExecDestroy(x);
     h->graphs.erase(h->graphs.begin());
@@ -1195,13 +1440,46 @@ int mt_rollout(mt_handle h, int n_steps, uint64_t seed, uint32_t step_idx0) {
   MT_ON_DEVICE(h, h->cfg.device);  // per-chain call: joins only where it has to (below)
   // several independent chains of launches (env ranges on separate streams) where that pays; a caller who is capturing
   // the handle's stream gets the plain single-stream sequence
-  int chains = (n_steps >= 2 && !h->trace) ? h->chains : 1;
-  if (chains > 1) {
-    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(h->stream, &st) != hipSuccess || st != hipStreamCaptureStatusNone) {
-      (void)hipGetLastError();
-      chains = 1;
+  const int chains = n_steps >= 2 ? usable_chains(h) : 1;
+  // Small shards: k steps per launch through the rollout kernels (kPolicy.multi_step_*).  The call exposes the state after
+  // n_steps steps and the outputs of the last one either way; every step still writes its outputs.
+  if (h->multi_k > 1 && n_steps >= 2 && fusable(h)) {
+    StepArgs a = h->args;
+    a.seed_lo = (uint32_t)seed;
+    a.seed_hi = (uint32_t)(seed >> 32);
+    int rc = MT_OK;
+    if (chains > 1) {
+      rc = fork_chains(h, chains);
+      if (rc) return rc;
+      const int64_t span = chain_span(h, chains);
+      hipStream_t root = h->stream;
+      for (int s0 = 0; s0 < n_steps; s0 += h->multi_k) {
+        const RolloutArgs r{std::min(h->multi_k, n_steps - s0), step_idx0 + (uint32_t)s0, 0u, h->cfg.radius};
+        for (int c = 0; c < chains; ++c) {
+          const int64_t off = (int64_t)c * span;
+          if (off >= h->n) continue;
+          h->stream = c == 0 ? root : h->chain_streams[c];
+          launch_rollout(h, args_for_range(h, a, off, std::min(span, h->n - off)), h->chain_rollout_split, r);
+        }
+      }
+      h->stream = root;
+      rc = check_launch(h, "rollout_kernel (mt_rollout, per chain)");
+      if (rc) return rc;
+      rc = settle_chains(h);
+    } else {
+      rc = join_chains(h);
+      if (rc) return rc;
+      for (int s0 = 0; s0 < n_steps; s0 += h->multi_k) {
+        const RolloutArgs r{std::min(h->multi_k, n_steps - s0), step_idx0 + (uint32_t)s0, 0u, h->cfg.radius};
+        launch_rollout(h, a, h->rollout_split, r);
+      }
+      rc = check_launch(h, "rollout_kernel (mt_rollout)");
     }
+    if (rc) return rc;
+    h->args.seed_lo = (uint32_t)seed;
+    h->args.seed_hi = (uint32_t)(seed >> 32);
+    h->args.major = step_idx0 + (uint32_t)(n_steps - 1);
+    return MT_OK;
   }
   bool graph = rollout_uses_graph(h, n_steps);
   if (graph && h->graph_mode < 0) {
@@ -1277,8 +1555,7 @@ int mt_rollout_fused(mt_handle h, int n_steps, uint64_t seed, uint32_t step_idx0
   if (n_steps == 0) return MT_OK;
   // The fused kernel implements the default trigonometry only; the measured alternatives run the same thing as a
   // sequence of launches.
-  const bool fusable = h->trig == 0 && !h->lds_table && !h->trace && !h->custom_frames;
-  if (!fusable) {
+  if (!fusable(h)) {
     for (int s = 0; s < n_steps; ++s) {
       int rc = mt_step_random(h, seed, step_idx0 + (uint32_t)s);
       if (rc) return rc;
@@ -1297,20 +1574,7 @@ int mt_rollout_fused(mt_handle h, int n_steps, uint64_t seed, uint32_t step_idx0
     if (rcg) return rcg;
   }
   RolloutArgs r{n_steps, step_idx0, auto_reset ? 1u : 0u, h->cfg.radius};
-  if (h->static_kind == 1)
-    launch_rollout_t<Ref4Table>(h, r);
-  else if (h->static_kind == 2)
-    launch_rollout_t<Dh7Table>(h, r);
-  else
-    switch (h->D) {
-      case 2: launch_rollout_t<RtTable<2>>(h, r); break;
-      case 3: launch_rollout_t<RtTable<3>>(h, r); break;
-      case 4: launch_rollout_t<RtTable<4>>(h, r); break;
-      case 5: launch_rollout_t<RtTable<5>>(h, r); break;
-      case 6: launch_rollout_t<RtTable<6>>(h, r); break;
-      case 7: launch_rollout_t<RtTable<7>>(h, r); break;
-      default: launch_rollout_t<RtTable<8>>(h, r); break;
-    }
+  launch_rollout(h, h->args, h->rollout_split, r);
   return check_launch(h, "rollout_kernel");
 }
 
@@ -1423,6 +1687,10 @@ int mt_set(mt_handle h, int field, const void* src, int64_t src_bytes) {
   const StepArgs& a = h->args;
   void* row = field == MT_F_TOTAL_REWARD ? (void*)a.total_reward : field == MT_F_DONE ? (void*)a.done :
               field == MT_F_EPISODES ? (void*)a.episodes : field == MT_F_LAST_RETURN ? (void*)a.last_return : nullptr;
+  if (field == MT_F_LAST_RETURN || field == MT_F_RETURN_RING) {  // rows an in-place exchange may still be reading
+    int rcg = order_behind_inplace_gather(h, h->stream);
+    if (rcg) return rcg;
+  }
   if (row) {  // single-row fields: env-major == SoA
     MT_HIP(h, hipMemcpyAsync(row, src, (size_t)need, hipMemcpyHostToDevice, h->stream));
     if (field == MT_F_DONE) {
@@ -1490,6 +1758,48 @@ int mt_timer_stop(mt_handle h, float* elapsed_ms) {
   MT_HIP(h, hipEventRecord(h->ev1, h->stream));
   MT_HIP(h, hipEventSynchronize(h->ev1));
   MT_HIP(h, hipEventElapsedTime(elapsed_ms, h->ev0, h->ev1));
+  return MT_OK;
+}
+
+int mt_timer_stop_async(mt_handle h) {
+  MT_REQUIRE(nullptr, h != nullptr, "handle is NULL");
+  MT_ON_DEVICE(h, h->cfg.device);  // NOT a join: one end event per stream that may still carry work of the handle
+  MT_HIP(h, hipEventRecord(h->ev1, h->stream));
+  h->timer_ends = 1;
+  if (h->forked)
+    for (int c = 1; c < h->chains; ++c) {
+      if (!h->chain_streams[c] || (int64_t)c * chain_span(h, h->chains) >= h->n) continue;
+      if (!h->ev1c[c]) MT_HIP(h, hipEventCreate(&h->ev1c[c]));
+      MT_HIP(h, hipEventRecord(h->ev1c[c], h->chain_streams[c]));
+      h->timer_ends = c + 1;
+    }
+  h->timer_with_gather = h->gather_pending;  // an exchange begun on the side stream ends at ev_g1
+  return MT_OK;
+}
+
+int mt_timer_read(mt_handle h, float* elapsed_ms) {
+  MT_REQUIRE(nullptr, h != nullptr, "handle is NULL");
+  MT_REQUIRE(h, elapsed_ms != nullptr, "elapsed_ms is NULL");
+  if (h->timer_ends < 1) return fail(h, MT_ERR_STATE, "mt_timer_read without mt_timer_stop_async");
+  MT_ON_DEVICE(h, h->cfg.device);
+  float best = 0.f, v = 0.f;
+  MT_HIP(h, hipEventSynchronize(h->ev1));
+  MT_HIP(h, hipEventElapsedTime(&best, h->ev0, h->ev1));
+  for (int c = 1; c < h->timer_ends; ++c) {
+    if (!h->ev1c[c]) continue;
+    MT_HIP(h, hipEventSynchronize(h->ev1c[c]));
+    MT_HIP(h, hipEventElapsedTime(&v, h->ev0, h->ev1c[c]));
+    best = v > best ? v : best;
+  }
+  if (h->timer_with_gather && h->ev_g1) {
+    MT_HIP(h, hipEventSynchronize(h->ev_g1));
+    if (hipEventElapsedTime(&v, h->ev0, h->ev_g1) == hipSuccess)
+      best = v > best ? v : best;  // (an exchange that ended before the timer started reads negative: ignored)
+    else
+      (void)hipGetLastError();
+  }
+  *elapsed_ms = best;
+  h->timer_ends = 0;
   return MT_OK;
 }
 
@@ -1684,6 +1994,64 @@ int mt_r_theta_batch(int device, const float* v1, const float* v2, int64_t n, fl
   if (e == hipSuccess) e = hipMemcpy(out_r_theta, dout, (size_t)n * 8, hipMemcpyDeviceToHost);
   if (e != hipSuccess) rc = fail(nullptr, MT_ERR_HIP, std::string("mt_r_theta_batch: ") + hipGetErrorString(e));
   return rc;
+}
+
+// The streaming yardstick of the step's own access shape (kernels.h: stream_probe_kernel): `reps` passes over n_envs envs
+// after 3 untimed ones, on a private stream, HIP events around them.  Allocates and frees its own buffers.
+int mt_stream_probe(int device, int dof, int n_targets, int64_t n_envs, int reps, float* us_per_pass, int64_t* bytes_per_pass) {
+  MT_REQUIRE(nullptr, us_per_pass != nullptr && bytes_per_pass != nullptr, "NULL argument");
+  MT_REQUIRE(nullptr, n_envs >= 256 && n_envs <= ((int64_t)1 << 30) - 256 && reps >= 1 && reps <= 100000, "n_envs / reps out of range");
+  const bool d4k7 = dof == 4 && n_targets == 7, d7k7 = dof == 7 && n_targets == 7, d4k10 = dof == 4 && n_targets == 10;
+  if (!(d4k7 || d7k7 || d4k10))
+    return fail(nullptr, MT_ERR_UNSUPPORTED, "mt_stream_probe: built for (dof, targets) = (4, 7), (7, 7), (4, 10)");
+  MT_ON_DEVICE(nullptr, device);
+  const int64_t ld = (int64_t)align_up((size_t)n_envs, 256) + 256;  // the arena's row pitch (mt_create)
+  const int RD = dof + 3 * n_targets + 2, WN = 3 * n_targets + 4;
+  float *state = nullptr, *out = nullptr;
+  uint8_t* bytes = nullptr;
+  hipStream_t st = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  hipError_t e = hipMalloc(&state, (size_t)RD * ld * 4);
+  if (e == hipSuccess) e = hipMalloc(&out, (size_t)WN * ld * 4);
+  if (e == hipSuccess) e = hipMalloc(&bytes, (size_t)ld);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipEventCreate(&e0);
+  if (e == hipSuccess) e = hipEventCreate(&e1);
+  if (e == hipSuccess) e = hipMemsetAsync(state, 0, (size_t)RD * ld * 4, st);
+  float ms = 0.f;
+  if (e == hipSuccess) {
+    auto pass = [&]() {
+      if (d4k7)
+        hipLaunchKernelGGL((stream_probe_kernel<4, 7>), grid_for(n_envs), dim3(kBlock), 0, st, state, out, bytes, n_envs, ld);
+      else if (d7k7)
+        hipLaunchKernelGGL((stream_probe_kernel<7, 7>), grid_for(n_envs), dim3(kBlock), 0, st, state, out, bytes, n_envs, ld);
+      else
+        hipLaunchKernelGGL((stream_probe_kernel<4, 10>), grid_for(n_envs), dim3(kBlock), 0, st, state, out, bytes, n_envs, ld);
+    };
+    for (int w = 0; w < 3; ++w) pass();
+    e = hipEventRecord(e0, st);
+    for (int r = 0; r < reps; ++r) pass();
+    if (e == hipSuccess) e = hipEventRecord(e1, st);
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e == hipSuccess) e = hipEventSynchronize(e1);
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+  }
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  if (st) {
+    (void)hipStreamSynchronize(st);
+    (void)hipStreamDestroy(st);
+  }
+  if (state) (void)hipFree(state);
+  if (out) (void)hipFree(out);
+  if (bytes) (void)hipFree(bytes);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(nullptr, e == hipErrorOutOfMemory ? MT_ERR_ALLOC : MT_ERR_HIP, std::string("mt_stream_probe: ") + hipGetErrorString(e));
+  }
+  *us_per_pass = ms * 1e3f / (float)reps;
+  *bytes_per_pass = (int64_t)(8 * dof + 24 * n_targets + 33) * n_envs;
+  return MT_OK;
 }
 
 }  // extern "C"

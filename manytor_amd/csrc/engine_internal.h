@@ -18,6 +18,11 @@ struct mt_engine {
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // mt_timer_stop_async / mt_timer_read: one end event per stream of the handle that may carry work (its stream, the
+  // chain streams while forked; a pending exchange on the side stream ends at ev_g1)
+  hipEvent_t ev1c[kMaxChains] = {nullptr, nullptr, nullptr, nullptr};  // [0] unused (= ev1)
+  int timer_ends = 0;              // end events recorded by the last mt_timer_stop_async: ev1 + ev1c[1 .. timer_ends-1]
+  bool timer_with_gather = false;  // ... and an exchange was pending then (its end = ev_g1)
   // mt_timer_lap_*: a lap = one begin event on the handle's stream + one end event per stream that carried work of the lap
   // (the handle's stream, and the chain streams while mt_rollout's chains are forked); its time = begin -> the latest end
   struct LapRec {
@@ -69,14 +74,21 @@ struct mt_engine {
   std::vector<RolloutGraph> graphs;
   std::vector<int> graph_seen;      // segment lengths asked for once: a graph is built at the second request
   uint32_t* graph_step0 = nullptr;  // device word: first step index of the segment being replayed
-  int graph_mode = -1;              // -1 by batch size, 0 never, 1 always (MT_GRAPH)
-  // mt_rollout as `chains` independent chains of launches (contiguous env ranges on separate streams): a step of env i
-  // depends only on env i's previous step, so while one range's kernel drains and its next one is dispatched the other
-  // ranges keep the chip busy (tools/multistream_probe.py, profiles/r03_variants.md).  Forked from and joined back to
-  // the handle's stream inside every mt_rollout call.
+  int graph_mode = -1;              // -1 by batch size (<= graph_max envs), 0 never, 1 always (MT_GRAPH)
+  int64_t graph_max = 131072;
+  // mt_rollout (and mt_step / mt_sample_actions / mt_set_actions from device memory) as `chains` independent chains of
+  // launches (contiguous env ranges on separate streams): a step of env i depends only on env i's previous step, so while
+  // one range's kernel drains and its next one is dispatched the other ranges keep the chip busy
+  // (tools/multistream_probe.py, profiles/r03_variants.md).  Forked lazily off the handle's stream by the first per-chain
+  // call and -- on the handle's own stream -- left forked across calls (see `forked` below): only the MT_ENTER calls and
+  // mt_sync join them; mt_device_ptr does not.
   int chains = 1;
   int chain_split = 0;          // the step-kernel schedule of a chain's launches is picked for the CHAIN's env count
   bool chain_prefetch = false;
+  int chain_rollout_split = 0;  // ... and the rollout-kernel schedule of a chain's multi-step launches
+  int multi_k = 1;              // mt_rollout: steps per launch on small shards (rollout kernels), 1 = one launch per step
+  std::string overrides;        // the MT_* overrides choose_dispatch saw ("NAME=value,...")
+  std::string describe;         // mt_describe_dispatch's text
   hipStream_t chain_streams[kMaxChains] = {nullptr, nullptr, nullptr, nullptr};  // [0] unused: chain 0 runs on `stream`
   hipEvent_t ev_fork = nullptr, ev_join[kMaxChains] = {nullptr, nullptr, nullptr, nullptr};
   // Chains stay forked ACROSS calls while the handle runs on its own stream: mt_rollout and mt_reset_random enqueue per

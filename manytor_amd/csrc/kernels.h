@@ -1899,4 +1899,35 @@ __global__ __launch_bounds__(kBlock) void r_theta_kernel(const float* v1, const 
   out[2 * (int64_t)i + 1] = atan2_deg_q1(h, d2);
 }
 
+// ---------------------------------------------------------------------------
+// Streaming yardstick (mt_stream_probe): the step kernel's memory operations with none of its arithmetic -- per env the
+// D + 3K + 2 state rows are read (goals, targets, alive mask, return), D + 2 of them are written back in place (plain
+// stores: goals, alive mask, return), and 3K + 4 output rows (obs, reward, end effector) plus one byte row (done) are
+// written with non-temporal stores: exactly the 8 D + 24 K + 33 bytes per env mt_step_random moves, with the same row
+// addressing (SGPR row base + 32-bit lane offset) and one env per lane.  What this kernel reaches on a box is what the
+// step kernel's access shape can reach there; bench.py quotes the step against it (roofline.achievable_gbs).
+// ---------------------------------------------------------------------------
+template <int D, int K>
+__global__ __launch_bounds__(kBlock) void stream_probe_kernel(float* state, float* out, uint8_t* bytes, int64_t n, int64_t ld) {
+  constexpr int RD = D + 3 * K + 2, WP = D + 2, WN = 3 * K + 4;
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  LaneOffset<true> o4{i * 4u}, o1{i};
+  if (i >= n) return;
+  float v[RD], acc = 0.f;
+#pragma unroll
+  for (int r = 0; r < RD; ++r) {
+    v[r] = ldr(state + (int64_t)r * ld, o4);
+    acc += v[r];
+  }
+  acc *= 1e-30f;  // keeps every load alive without letting the state drift
+#pragma unroll
+  for (int r = 0; r < WN; ++r) str_stream(out + (int64_t)r * ld, o4, v[r % RD] + acc);
+#pragma unroll
+  for (int r = 0; r < WP; ++r) {  // the rows the step rewrites in place: goals (rows 0 .. D-1) and the last two
+    const int row = r < D ? r : RD - 2 + (r - D);
+    str(state + (int64_t)row * ld, o4, v[row] + acc);
+  }
+  str_stream(bytes, o1, (uint8_t)(acc > 1.f ? 1 : 0));
+}
+
 }  // namespace mt

@@ -133,7 +133,9 @@ class HostBarrier:
         except FileNotFoundError:
             pass
 
-    def wait(self, timeout_s: float = 300.0):
+    def wait(self, timeout_s: float = 300.0, sleep_s: float = 0.0):
+        """Enter the barrier; returns when every rank has.  sleep_s > 0: poll asleep instead of spinning -- for a wait that
+        is expected to be long and must leave the cores to somebody else (bench.py: rank 0's CPU baseline)."""
         import time
         self.epoch += 1
         self._slots[self.rank, 0] = self.epoch
@@ -141,7 +143,9 @@ class HostBarrier:
         spins, t0 = 0, None
         while int(col.min()) < self.epoch:
             spins += 1
-            if spins & 0x3FF == 0:             # be polite if ranks outnumber cores, and never spin for ever
+            if sleep_s > 0.0:
+                time.sleep(sleep_s)
+            if sleep_s > 0.0 or spins & 0x3FF == 0:   # be polite if ranks outnumber cores, and never spin for ever
                 time.sleep(0)
                 now = time.monotonic()
                 t0 = now if t0 is None else t0
@@ -267,6 +271,7 @@ def gloo_gather_returns(local_returns, n_total: int, group=None):
 def attach_gloo_gather(engine, n_total: int, rank: int, world_size: int, group=None):
     """bench.py --rehearsal: replace engine.gather_returns by device -> host -> gloo all-gather -> device, so that two
     ranks sharing one GPU can run the N > 1 control flow.  Never used when real GPUs per rank are available."""
+    import numpy as np
     import torch
 
     def gather_returns(out=None, field=None, row=0):

@@ -136,6 +136,14 @@ class StepEngine:
             raise RuntimeError("StepEngine is closed")
         return self._lib.mt_step_kernel_name(self._h).decode()
 
+    def dispatch(self) -> dict:
+        """The dispatch of this engine as data (mt_describe_dispatch): the schedule resolved for every entry point, the
+        MT_* overrides in effect and the library's table of size thresholds."""
+        import json
+        if not self._h:
+            raise RuntimeError("StepEngine is closed")
+        return json.loads(self._lib.mt_describe_dispatch(self._h).decode())
+
     # ---- stream / sync / timing ---------------------------------------------------------------
     def set_stream(self, hip_stream):
         """Run on a caller-owned hipStream_t (int / pointer).  0 is the legacy default stream (torch's default
@@ -160,6 +168,17 @@ class StepEngine:
     def timer_stop(self) -> float:
         ms = C.c_float(0)
         self._call(self._lib.mt_timer_stop, C.byref(ms))
+        return ms.value
+
+    def timer_stop_async(self):
+        """End mark of timer_start without joining the chains or waiting on the host; timer_read() waits and returns."""
+        self._call(self._lib.mt_timer_stop_async)
+
+    def timer_read(self) -> float:
+        """Device milliseconds from timer_start to the last end event of timer_stop_async (all streams of the engine,
+        incl. an exchange that was pending on the side stream)."""
+        ms = C.c_float(0)
+        self._call(self._lib.mt_timer_read, C.byref(ms))
         return ms.value
 
     def lap_begin(self):
@@ -557,6 +576,15 @@ def comm_unique_id() -> bytes:
 
 
 # ---- stateless helpers = module functions of the reference (manytor.py:17-53) -------------------
+def stream_probe(n_envs, dof=4, obj_number=7, reps=50, device=0):
+    """(us per pass, bytes per pass) of the streaming yardstick: the memory operations of one step_random over n_envs
+    envs -- same rows, same stores, same addressing -- without its arithmetic (mt_stream_probe)."""
+    us, nbytes = C.c_float(0), C.c_int64(0)
+    L.check(L.load().mt_stream_probe(int(device), int(dof), int(obj_number), C.c_int64(int(n_envs)), int(reps), C.byref(us),
+                                     C.byref(nbytes)))
+    return us.value, nbytes.value
+
+
 def fk_batch(mode, angles, dh_table=REF_DH_TABLE, radians=False, device=0) -> np.ndarray:
     lib = L.load()
     table = np.ascontiguousarray(np.asarray(dh_table, dtype=np.float32))

@@ -208,6 +208,15 @@ class _FakeEngine:
         assert self.laps[-1] == what
 
     # the rest of what bench.measure / bench.TimedEngine ask of an engine
+    def timer_start(self):
+        self.t_start = self.launches
+
+    def timer_stop_async(self):
+        self.t_stop = self.launches
+
+    def timer_read(self):
+        return 0.01 * (self.t_stop - self.t_start)        # "device milliseconds" of the region: 10 us per step
+
     def lap_times(self):
         n, self.laps = len(self.laps), []
         return [0.05] * n                                 # "device milliseconds" per lap
@@ -288,8 +297,15 @@ def test_bench_measure_protocol_world2_gloo(phase):
     out = _spawn(_measure_worker, (20, 5, phase))
     for key, (res, launches, gathers) in out.items():
         for k in ("elapsed", "ms_per_step", "ms_per_step_min", "ms_per_step_max", "step_us", "launches", "gather_us",
-                  "gathers_per_region", "repeats", "prewarm", "episode_len", "value"):
+                  "gathers_per_region", "repeats", "prewarm", "episode_len", "value", "value_device_timeline",
+                  "region_device_ms", "device_ms_per_step", "steps_per_kernel_launch"):
             assert k in res, (key, k)
+        # the device timeline of a region: the stand-in reports 10 us per step between the start mark (after the opening
+        # fence) and the end mark (before the closing one) -> exactly the region's 20 steps on both ranks
+        assert res["region_device_ms"] == pytest.approx(0.2) and res["device_ms_per_step"] == pytest.approx(0.01)
+        n_total = {"weak": 1200, "strong_1m": 1001, "config3": 4003}[key]
+        assert res["value_device_timeline"] == pytest.approx(n_total * 20 / 0.2e-3)
+        assert res["steps_per_kernel_launch"] == 1
         assert res["episode_len"] == 20 and res["gathers_per_region"] == 1 and res["repeats"] >= 5
         assert res["launches"] == 20 * res["repeats"]
         assert launches == res["prewarm"] + 5 + phase + 20 * res["repeats"]
@@ -297,3 +313,105 @@ def test_bench_measure_protocol_world2_gloo(phase):
         # aligned after the warm-up, a 20-step region is ONE step segment = one 0.05 ms lap; started half-way through an
         # episode it is two segments around the episode end = two laps
         assert res["step_us"] == pytest.approx((50.0 if phase == 0 else 100.0) / 20)
+
+
+# ---- bench.py starts its own ranks -------------------------------------------------------------------
+def test_bench_launch_dry_run_prints_the_children():
+    """`python bench.py --gpus 2 --steps 20 --warmup 5` with no launcher around it: the parent only plans / starts the
+    ranks.  --launch-dry-run prints the children's argv and rank environment; nothing imports torch or touches a GPU."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5",
+                          "--launch-dry-run"], capture_output=True, text=True, timeout=60, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    plan = json.loads(out.stdout)
+    kids = plan["children"]
+    assert len(kids) == 2
+    ports = set()
+    for r, kid in enumerate(kids):
+        assert kid["argv"][0] == sys.executable and kid["argv"][1] == os.path.join(ROOT, "bench.py")
+        assert kid["argv"][2:] == ["--gpus", "2", "--steps", "20", "--warmup", "5"]          # the dry-run flag does not travel
+        e = kid["env"]
+        assert e["RANK"] == str(r) and e["LOCAL_RANK"] == str(r) and e["WORLD_SIZE"] == "2"
+        assert e["MASTER_ADDR"] == "127.0.0.1" and e["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+        ports.add(e["MASTER_PORT"])
+    assert len(ports) == 1 and 1024 < int(ports.pop()) < 65536
+    # under a launcher (WORLD_SIZE set) the script is a rank, never a launcher
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-dry-run"],
+                         capture_output=True, text=True, timeout=60, env={**env, "WORLD_SIZE": "2", "RANK": "0"})
+    assert out.returncode == 0 and json.loads(out.stdout)["children"] == []
+
+
+_STUB = r"""
+import json, os, sys, time
+rank = int(os.environ["RANK"]); world = int(os.environ["WORLD_SIZE"])
+mode = sys.argv[sys.argv.index("--mode") + 1]
+assert os.environ["MASTER_ADDR"] == "127.0.0.1" and int(os.environ["MASTER_PORT"]) > 0 and os.environ["LOCAL_RANK"] == str(rank)
+print(f"chatter of rank {rank}")                       # native libraries write to stdout too
+if mode == "ok":
+    if rank == 0:
+        print(json.dumps({"metric": "m", "value": 1.0, "n_gpus": world}))
+    sys.exit(0)
+if mode == "rank1_fails":
+    if rank == 1:
+        sys.exit(3)
+    time.sleep(60)                                     # the launcher has to end this one
+if mode == "hang":
+    time.sleep(60)
+"""
+
+
+@pytest.mark.parametrize("mode,rc", [("ok", 0), ("rank1_fails", 3), ("hang", 124)])
+def test_bench_self_launch_relays_rank0_and_ends_the_group(mode, rc, tmp_path, capfd):
+    """bench.self_launch with a stand-in rank script: rank 0's JSON line -- and only it -- reaches stdout, a failing rank or
+    the timeout ends every other rank (each child leads its own process group) and sets the exit code."""
+    import time
+    sys.path.insert(0, ROOT)
+    import bench
+    stub = tmp_path / "rank_stub.py"
+    stub.write_text(_STUB)
+    t0 = time.monotonic()
+    got = bench.self_launch(["--gpus", "3", "--mode", mode], 3, timeout_s=3.0 if mode == "hang" else 60.0, script=str(stub))
+    took = time.monotonic() - t0
+    out, err = capfd.readouterr()
+    assert got == rc
+    assert took < 30.0                                       # nobody waited for the sleeping ranks
+    if mode == "ok":
+        assert out.count("\n") == 1 and '"metric": "m"' in out and '"n_gpus": 3' in out
+        for r in range(3):
+            assert f"chatter of rank {r}" in err              # everything else went to stderr
+    else:
+        assert out == ""
+        assert ("rank 1 exited with 3" in err) if mode == "rank1_fails" else ("timeout" in err)
+
+
+def _ring_gather_worker(rank, world, port, q):
+    """the gloo stand-in gathering a 2-D field (a return-ring row) used numpy without importing it."""
+    sys.path.insert(0, ROOT)
+    r, _, w = _init(rank, world, port)
+    n_total = 11
+    base, n = D.shard_range(n_total, r, w)
+
+    class Eng:                                            # what attach_gloo_gather needs of a StepEngine
+        device = "cpu"
+
+        def get(self, field):
+            ids = np.arange(base, base + n, dtype=np.float32)
+            return ids if field != 13 else np.stack([ids, 100 + ids, 200 + ids], axis=1)   # MT_F_RETURN_RING: (n, R)
+
+    eng = D.attach_gloo_gather(Eng(), n_total, r, w)
+    out = torch.empty(n_total)
+    eng.gather_returns(out, field=13, row=2)
+    flat = torch.empty(n_total)
+    eng.gather_returns(flat)
+    if r == 0:
+        q.put((out.numpy().copy(), flat.numpy().copy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gloo_stand_in_gathers_a_return_ring_row():
+    ring, flat = _spawn(_ring_gather_worker, ())
+    np.testing.assert_array_equal(ring, 200 + np.arange(11, dtype=np.float32))
+    np.testing.assert_array_equal(flat, np.arange(11, dtype=np.float32))
