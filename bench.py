@@ -845,7 +845,7 @@ def main():
     if rank == 0:
         step_s = r["step_us"] * 1e-6                            # device time of one step of this rank's envs (HIP events)
         # mt_rollout may run a step as several concurrent launches on env ranges (the dispatch says so)
-        chains = 1 if args.fused else int(dispatch["chains"]["count"])
+        chains = 1 if args.fused else int(dispatch["rollout"]["chains"])
         envs_per_launch = n_local if chains == 1 else int(dispatch["chains"]["span"])
         spl = r["steps_per_kernel_launch"]                      # 1 = one launch per step; L for --fused; k on small shards
         moved = moved_bytes_per_env_step(args.dof, args.targets, spl)
@@ -938,19 +938,29 @@ def main():
                     "actions are written by a separate mt_sample_actions launch (per chain as well) whose own time "
                     "(sample_actions_us, measured in the same per-chain form) is subtracted; *_pair = the (sample, step) pair "
                     "as timed, against the bytes of both launches (SURVEY's 249 + the 4 D-byte action write)"}
-        # BASELINE.json's other single-GPU configurations and the pure-HBM point, same kernel path, short runs
+        # BASELINE.json's other single-GPU configurations and the pure-HBM point, same kernel path, short runs.  Every
+        # configuration is measured on two fresh engines, once in this order and once more in the reverse order at the end:
+        # how fast an arena streams depends on where its pages physically landed, which depends on the allocations the
+        # process made before (the same configuration read 38 or 102-192 us by its position in this
+        # list), so one window per configuration is not a measurement.  us_per_step = the faster pass, both are listed.
+        others = (("configs[1]: 65536 arms, 4-DoF", 65536, m.REF_DH_TABLE, 51.3),
+                  ("131072 arms, 4-DoF (1 M arms over 8 GPUs, per-GPU shard)", 131072, m.REF_DH_TABLE, 51.3),
+                  ("524288 arms, 4-DoF (configs[3] over 8 GPUs, per-GPU shard)", 524288, m.REF_DH_TABLE, 51.3),
+                  ("configs[4]: 1048576 arms, 7-DoF table", 1048576, m.DH7_TABLE, 92.6),
+                  ("4194304 arms, 4-DoF (1 GB working set: pure HBM regime)", 4194304, m.REF_DH_TABLE, 51.3))
+        passes = {}
+        for order in (others, others[::-1]):
+            for label, n2, tbl, rad in order:
+                passes.setdefault(label, []).append(time_step_launches(m, n2, tbl, rad, args.targets, dev, args.seed,
+                                                                       steps=300 if n2 > (1 << 21) else 600, want_spl=True))
         out["secondary"]["other_configs"] = {}
-        for label, n2, tbl, rad in (("configs[1]: 65536 arms, 4-DoF", 65536, m.REF_DH_TABLE, 51.3),
-                                    ("131072 arms, 4-DoF (1 M arms over 8 GPUs, per-GPU shard)", 131072, m.REF_DH_TABLE, 51.3),
-                                    ("524288 arms, 4-DoF (configs[3] over 8 GPUs, per-GPU shard)", 524288, m.REF_DH_TABLE, 51.3),
-                                    ("4194304 arms, 4-DoF (1 GB working set: pure HBM regime)", 4194304, m.REF_DH_TABLE, 51.3),
-                                    ("configs[4]: 1048576 arms, 7-DoF table", 1048576, m.DH7_TABLE, 92.6)):
-            us, kname, spl2 = time_step_launches(m, n2, tbl, rad, args.targets, dev, args.seed,
-                                                 steps=300 if n2 > (1 << 21) else 600, want_spl=True)
+        for label, n2, tbl, rad in others:
+            us, kname, spl2 = min(passes[label], key=lambda p_: p_[0])
             b2 = algorithmic_bytes_per_env_step(len(tbl), args.targets)
             b2a = moved_bytes_per_env_step(len(tbl), args.targets, spl2)
             gbs = b2a * n2 / (us * 1e-6) / 1e9
-            rec = {"us_per_step": us, "kernel": kname, "env_steps_per_s": n2 / (us * 1e-6), "steps_per_kernel_launch": spl2,
+            rec = {"us_per_step": us, "us_per_step_passes": [p_[0] for p_ in passes[label]], "kernel": kname,
+                   "env_steps_per_s": n2 / (us * 1e-6), "steps_per_kernel_launch": spl2,
                    "bytes_per_env_step": b2a, "frac_of_hbm_peak": gbs / HBM_PEAK_GBS,
                    "bytes_per_env_step_survey_model": b2,
                    "frac_survey_model": b2 * n2 / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, "regime": regime_of(n2, b2a)}

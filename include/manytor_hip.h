@@ -164,6 +164,9 @@ MT_API int mt_sync(mt_handle h);
  * env-major or (3K, ld) SoA, in host or device memory.
  * mt_reset_random: targets rejection-sampled on the device (Philox-4x32-10 keyed by
  * seed / global env id / episode), same law as manytor.py:229-239. */
+/* Host arrays are screened: a NaN or an infinite coordinate is MT_ERR_INVALID_ARG and nothing is written.  Targets handed
+ * over in device memory cannot be screened on the host: the reset kernel drops an unusable one (dead from the start,
+ * coordinates zeroed) and counts it (mt_bad_action_count). */
 MT_API int mt_reset(mt_handle h, const float* points, int layout, int is_device);
 MT_API int mt_reset_random(mt_handle h, uint64_t seed, uint32_t episode);
 /* Re-arm only the envs whose done byte is 1: their return goes to MT_F_LAST_RETURN and into MT_F_RETURN_RING, their
@@ -200,7 +203,8 @@ MT_API int mt_step_host(mt_handle h, const void* actions, int dtype, float* obs,
 MT_API int mt_env_step(mt_handle h, int64_t env, const float* action, float* obs, int32_t* reward, uint8_t* done);
 /* Number of (env, step) pairs so far whose staged action was not a finite angle of magnitude <= 32768 degrees (NaN,
  * +-inf from a diverging policy ...).  Such an env holds its pose for that step instead of poisoning its state.
- * Synchronises.  The reference has no such check (numpy would propagate the NaN into goals, manytor.py:184). */
+ * Synchronises.  The reference has no such check (numpy would propagate the NaN into goals, manytor.py:184).
+ * Also counts the targets mt_reset dropped because a coordinate handed over in device memory was NaN / infinite. */
 MT_API int mt_bad_action_count(mt_handle h, uint64_t* count);
 /* The same with the action drawn in-kernel (results bit-identical to mt_sample_actions followed by
  * mt_step).  The drawn action is not stored in MT_F_ACTIONS: it is the new MT_F_GOALS (goals = action after a
@@ -208,9 +212,9 @@ MT_API int mt_bad_action_count(mt_handle h, uint64_t* count);
 MT_API int mt_step_random(mt_handle h, uint64_t seed, uint32_t step_idx);
 /* n_steps x mt_step_random with step indices step_idx0, step_idx0+1, ... (the
  * inner loop of test_multi.py:19-21).  The call exposes the state after n_steps steps and the outputs of the LAST one
- * (obs, reward, done, end effector), so on small shards (<= 262 144 envs) it runs FOUR steps per launch through the
+ * (obs, reward, done, end effector), so on small shards (<= 131 072 envs) it runs FIVE steps per launch through the
  * kernels of mt_rollout_fused -- joint angles, alive mask and return in registers, targets in LDS between them; every
- * step still computes and writes its outputs -- bit-identical to the launch-per-step sequence, without three of four
+ * step still computes and writes its outputs -- bit-identical to the launch-per-step sequence, without four of five
  * kernel boundaries and state re-fetches (MT_ROLLOUT_K=1 gives one launch per step back; then batches <= 131 072 envs are
  * replayed from a HIP graph that the handle captures once per segment length).
  * On large batches (163 840 .. 3 M envs) the call runs as TWO independent chains of launches -- the two halves of the env

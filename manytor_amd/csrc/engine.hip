@@ -149,8 +149,19 @@ struct DispatchPolicy {
   // per step is a kernel boundary plus a re-fetch of the whole state past L2 for 4-6 us of work -- it runs
   // `multi_step_k` steps per launch through the rollout kernels (state in registers / LDS between them; every step
   // still writes its obs / reward / done / ee), bit-identical by construction             [r04_variants.md 1]
+  //   us per step, 50-step segments from an idle device (tools/rollout_k_sweep.py, profiles/r04_rollout_k_sweep*.json):
+  //                 one launch per step (default of round 3)      k = 4     k = 5     k = 8     k = 50
+  //      65 536 envs   5.71 (graph replay)                         4.18      3.99      3.74      3.04
+  //      98 304        6.48 (graph replay)                         4.96      4.70      4.35
+  //     131 072        6.47 (graph replay)                         5.79      5.50      5.10      4.42
+  //     163 840        7.43 (two chains of step kernels)           6.59      6.26      5.88
+  //     196 608        8.32 (two chains)                           6.74      6.35      5.97
+  //     262 144        8.09 (two chains)                           8.03      7.64      7.27
+  //   (k = 2 loses at 131 072: a rollout-kernel launch costs 4-6 us before its first step's outputs.)  The multi-step
+  //   launches run on the handle's stream alone: in two chains they are faster back to back at 131 072-163 840 envs
+  //   (4.78 / 5.88 us) but slower from an idle device over a 20-step segment (5.83 / 6.81) and slower at >= 196 608.
   int64_t multi_step_max = 262144;
-  int multi_step_k = 4;
+  int multi_step_k = 5;
   // the angle-addition recurrence is run (S - 1) / 2 rotations from each end of a route; beyond this many the per-pose
   // polynomial sincos kernels take over (drift: 12 rotations 3.3e-5 / 6.6e-5 in z on the 4- / 7-joint arm, 31 rotations
   // 8.6e-5 / 1.3e-4, outside the 1e-4 position tolerance)                                [tests/test_gpu_zmin.py]
@@ -264,8 +275,10 @@ static void choose_dispatch(mt_handle h) {
 
   // ---- mt_rollout / mt_step as independent chains of launches on separate streams (engine_internal.h) ----
   h->chains = (n >= P.chains_min && n <= P.chains_max) ? 2 : 1;
+  h->chains_forced = false;
   if (env_int("MT_CHAINS", &v)) {
     h->chains = (int)std::max<long long>(1, std::min<long long>(mt_engine::kMaxChains, v));
+    h->chains_forced = true;
     seen("MT_CHAINS");
   }
   if (n < 2 * 256) h->chains = 1;
@@ -280,6 +293,12 @@ static void choose_dispatch(mt_handle h) {
   if (env_int("MT_ROLLOUT_K", &v)) {
     h->multi_k = (int)std::max<long long>(1, std::min<long long>(64, v));
     seen("MT_ROLLOUT_K");
+  }
+  // ... whose launches take the prologue that runs the first step under the state loads (kernels.h RPF; static tables)
+  h->rollout_early = true;
+  if (env_int("MT_ROLLOUT_EARLY", &v)) {
+    h->rollout_early = v != 0;
+    seen("MT_ROLLOUT_EARLY");
   }
 
   if (h->custom_frames) {
@@ -581,40 +600,42 @@ void launch_joints_d(mt_handle h, float* out) {
 }
 
 // The rollout kernels on the envs `a` describes (the whole batch or a chain's 256-aligned range), `split` lanes per env.
-template <class Tbl, int L>
+// RPF (kernels.h): the prologue that requests everything up front and runs the first step under the loads -- for the short
+// launches of mt_rollout's multi-step form, compile-time tables only (the long fused launches keep RPF = 0).
+template <class Tbl, int L, int RPF>
 void launch_rollout_split_t(mt_handle h, const StepArgs& a, const RolloutArgs& r) {
   const int64_t per_block = kBlock / L;
   const size_t lds = (size_t)3 * h->K * per_block * sizeof(float) + (ActionTrigTable<Tbl>::value ? kTrigEntries * sizeof(SinCos) : 0);
   if (lds > 65536)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_split_kernel<Tbl, L>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_split_kernel<Tbl, L, RPF>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((rollout_split_kernel<Tbl, L>), dim3((unsigned)((a.n + per_block - 1) / per_block)), dim3(kBlock), lds,
+  hipLaunchKernelGGL((rollout_split_kernel<Tbl, L, RPF>), dim3((unsigned)((a.n + per_block - 1) / per_block)), dim3(kBlock), lds,
                      h->stream, a, r);
 }
 
-template <class Tbl>
+template <class Tbl, int RPF>
 void launch_rollout_t(mt_handle h, const StepArgs& a, int split, const RolloutArgs& r) {
-  if (split == 4) return launch_rollout_split_t<Tbl, 4>(h, a, r);
-  if (split == 2) return launch_rollout_split_t<Tbl, 2>(h, a, r);
+  if (split == 4) return launch_rollout_split_t<Tbl, 4, RPF>(h, a, r);
+  if (split == 2) return launch_rollout_split_t<Tbl, 2, RPF>(h, a, r);
   // 21.5 KB at K = 7, 96 KB at K = 32 (of 160 KB), + 3.6 KB for the action sin / cos table of the compile-time tables
   const size_t lds = (size_t)3 * h->K * kBlock * sizeof(float) + (ActionTrigTable<Tbl>::value ? kTrigEntries * sizeof(SinCos) : 0);
   if (lds > 65536)  // above the default dynamic-LDS limit the kernel has to be told
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_kernel<Tbl>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_kernel<Tbl, RPF>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((rollout_kernel<Tbl>), grid_for(a.n), dim3(kBlock), lds, h->stream, a, r);
+  hipLaunchKernelGGL((rollout_kernel<Tbl, RPF>), grid_for(a.n), dim3(kBlock), lds, h->stream, a, r);
 }
 
-void launch_rollout(mt_handle h, const StepArgs& a, int split, const RolloutArgs& r) {
-  if (h->static_kind == 1) return launch_rollout_t<Ref4Table>(h, a, split, r);
-  if (h->static_kind == 2) return launch_rollout_t<Dh7Table>(h, a, split, r);
+void launch_rollout(mt_handle h, const StepArgs& a, int split, const RolloutArgs& r, bool early = false) {
+  if (h->static_kind == 1) return early ? launch_rollout_t<Ref4Table, kPrefetch>(h, a, split, r) : launch_rollout_t<Ref4Table, 0>(h, a, split, r);
+  if (h->static_kind == 2) return early ? launch_rollout_t<Dh7Table, kPrefetch>(h, a, split, r) : launch_rollout_t<Dh7Table, 0>(h, a, split, r);
   switch (h->D) {
-    case 2: launch_rollout_t<RtTable<2>>(h, a, split, r); break;
-    case 3: launch_rollout_t<RtTable<3>>(h, a, split, r); break;
-    case 4: launch_rollout_t<RtTable<4>>(h, a, split, r); break;
-    case 5: launch_rollout_t<RtTable<5>>(h, a, split, r); break;
-    case 6: launch_rollout_t<RtTable<6>>(h, a, split, r); break;
-    case 7: launch_rollout_t<RtTable<7>>(h, a, split, r); break;
-    default: launch_rollout_t<RtTable<8>>(h, a, split, r); break;
+    case 2: launch_rollout_t<RtTable<2>, 0>(h, a, split, r); break;
+    case 3: launch_rollout_t<RtTable<3>, 0>(h, a, split, r); break;
+    case 4: launch_rollout_t<RtTable<4>, 0>(h, a, split, r); break;
+    case 5: launch_rollout_t<RtTable<5>, 0>(h, a, split, r); break;
+    case 6: launch_rollout_t<RtTable<6>, 0>(h, a, split, r); break;
+    case 7: launch_rollout_t<RtTable<7>, 0>(h, a, split, r); break;
+    default: launch_rollout_t<RtTable<8>, 0>(h, a, split, r); break;
   }
 }
 
@@ -760,6 +781,10 @@ int mt_create(mt_handle* out, const mt_config* cfg) {
   MT_REQUIRE(nullptr, cfg->n_targets >= 1 && cfg->n_targets <= MT_MAX_TARGETS, "n_targets must be in 1..32");
   MT_REQUIRE(nullptr, cfg->substeps >= 2, "substeps must be >= 2");
   MT_REQUIRE(nullptr, cfg->pickup_tol >= 0.f && cfg->radius > 0.f, "pickup_tol/radius out of range");
+  // the kernels are built with -ffinite-math-only: every float that reaches them is screened on its bit pattern at the door
+  MT_REQUIRE(nullptr, first_unusable(&cfg->pickup_tol, 1, kMaxFiniteBits) < 0 && first_unusable(&cfg->radius, 1, kMaxFiniteBits) < 0,
+             "pickup_tol / radius must be finite");
+  MT_REQUIRE(nullptr, first_unusable(cfg->dh_table, (int64_t)cfg->dof * 4, kMaxFiniteBits) < 0, "dh_table holds a NaN or an infinity");
   MT_REQUIRE(nullptr, cfg->env_id_base >= 0, "env_id_base must be >= 0");
   MT_REQUIRE(nullptr, cfg->return_ring >= 0 && cfg->return_ring <= MT_MAX_RETURN_RING, "return_ring must be in 0..64");
   MT_REQUIRE(nullptr, cfg->reserved == 0, "mt_config.reserved must be 0");
@@ -824,6 +849,9 @@ int mt_create(mt_handle* out, const mt_config* cfg) {
                o_trace = take((cfg->flags & MT_FLAG_TRACE) ? (size_t)cfg->substeps * 3 * ld * 4 : 0),
                o_zmin = take((cfg->flags & MT_FLAG_DEBUG_ZMIN) ? ld * 4 : 0), o_trig = take(kTrigEntries * sizeof(SinCos));
   h->arena_bytes = off;
+  // (One experiment with hipExtMallocWithFlags(hipDeviceMallocContiguous) instead -- a physically contiguous arena -- did not
+  // remove the placement-dependent slow arenas described in DESIGN.md section 5 and cost 5 % at 1 M arms: dropped the same
+  // day, profiles/r04_variants.md section 3.)
   if (hipMalloc(&h->arena, h->arena_bytes) != hipSuccess) {
     (void)hipGetLastError();
     return bail(MT_ERR_ALLOC, "hipMalloc of the state arena failed (" + std::to_string(h->arena_bytes) + " bytes)");
@@ -921,7 +949,7 @@ const char* mt_step_kernel_name(mt_handle h) {
                         step_blocks_per_cu(h, chain_span(h, h->chains)) > 0)
                            ? ", " + std::to_string(step_blocks_per_cu(h, chain_span(h, h->chains))) + " blocks/CU" : std::string()) + "]";
   if (h->multi_k > 1 && fusable(h)) {  // what mt_rollout launches on small shards instead of one step kernel per step
-    const int sp = h->chains > 1 ? h->chain_rollout_split : h->rollout_split;
+    const int sp = (h->chains > 1 && h->chains_forced) ? h->chain_rollout_split : h->rollout_split;
     h->kernel_name += " [mt_rollout: " + std::to_string(h->multi_k) + " steps per launch, " +
                       (sp ? "rollout_split_kernel L=" + std::to_string(sp) : std::string("rollout_kernel")) + "]";
   }
@@ -955,7 +983,8 @@ const char* mt_describe_dispatch(mt_handle h) {
       ",\"blocks_per_cu\":" + num(h->chains > 1 && rec && !h->chain_split && h->chain_prefetch && h->trig_steps ? step_blocks_per_cu(h, span) : 0) + "}" +
       ",\"rollout\":{\"form\":\"" + (multi ? "multi_step" : (h->chains > 1 ? "chained_steps" : (graph ? "graph_replay" : "launch_per_step"))) +
       "\",\"steps_per_launch\":" + num(multi ? h->multi_k : 1) + ",\"graph\":" + b(!multi && graph) +
-      ",\"lanes_per_env\":" + num(std::max(1, multi ? (h->chains > 1 ? h->chain_rollout_split : h->rollout_split) : (rec ? (h->chains > 1 ? h->chain_split : h->split) : 0))) + "}" +
+      ",\"lanes_per_env\":" + num(std::max(1, multi ? ((h->chains > 1 && h->chains_forced) ? h->chain_rollout_split : h->rollout_split) : (rec ? (h->chains > 1 ? h->chain_split : h->split) : 0))) +
+      ",\"chains\":" + num(multi && !h->chains_forced ? 1 : h->chains) + "}" +
       ",\"fused\":{\"usable\":" + b(fusable(h)) + ",\"lanes_per_env\":" + num(h->rollout_split ? h->rollout_split : 1) + "}" +
       ",\"reset\":{\"lanes_per_env\":" + num(h->reset_split ? 4 : 1) + "}" +
       ",\"overrides\":\"" + h->overrides + "\"" +
@@ -967,7 +996,8 @@ const char* mt_describe_dispatch(mt_handle h) {
       ",\"chain_prefetch_other_max\":" + num(P.chain_prefetch_other_max) + ",\"flat_from\":" + num(P.flat_from) +
       ",\"block_caps\":" + caps + ",\"multi_step_max\":" + num(P.multi_step_max) + ",\"multi_step_k\":" + num(P.multi_step_k) +
       ",\"max_recurrence_rotations\":" + num(P.max_recurrence_rotations) + ",\"ld_pad_above\":" + num(P.ld_pad_above) +
-      ",\"ld_pad_floats\":" + num(P.ld_pad_floats) + "}}";
+      ",\"ld_pad_floats\":" + num(P.ld_pad_floats) + "}" +
+      ",\"arena_bytes\":" + num((long long)h->arena_bytes) + "}";
   return d.c_str();
 }
 
@@ -1008,6 +1038,14 @@ int mt_reset(mt_handle h, const float* points, int layout, int is_device) {
     const int64_t bad = first_unusable(points, h->n * 3 * h->K, kMaxFiniteBits);
     if (bad >= 0) return fail(h, MT_ERR_INVALID_ARG, "mt_reset: points element " + std::to_string(bad) + " is NaN or infinite");
   }
+  if (!is_device && layout == MT_SOA)
+    for (int r = 0; r < 3 * h->K; ++r) {  // the n live columns of every row (the pad is the caller's garbage)
+      const int64_t bad = first_unusable(points + (int64_t)r * h->ld, h->n, kMaxFiniteBits);
+      if (bad >= 0)
+        return fail(h, MT_ERR_INVALID_ARG, "mt_reset: points row " + std::to_string(r) + " element " + std::to_string(bad) + " is NaN or infinite");
+    }
+  // (targets handed over in DEVICE memory cannot be screened here: reset_kernel drops an unusable one -- dead from the
+  // start, coordinates zeroed -- and counts it, see mt_bad_action_count)
   MT_ENTER(h);
   const int rows = 3 * h->K;
   if (layout == MT_SOA) {
@@ -1048,7 +1086,9 @@ static int reset_random_impl(mt_handle h, uint64_t seed, uint32_t episode, int m
   MT_ON_DEVICE(h, h->cfg.device);
   // A full random reset of a multi-chain handle is issued per chain, behind that chain's own last step, and leaves the
   // chains forked: one range's reset runs beside the other range's last step instead of behind a join.
-  const bool per_chain = mode == 1 && h->chains > 1 && h->lazy_chains;
+  // (only WHILE they are forked: behind a joined call -- the multi-step mt_rollout of small shards, a getter -- the reset
+  // is one launch on the handle's stream, and whoever forks next forks behind it)
+  const bool per_chain = mode == 1 && h->chains > 1 && h->lazy_chains && h->forked;
   if (!per_chain) {
     int rc = join_chains(h);
     if (rc) return rc;
@@ -1311,6 +1351,8 @@ int mt_env_reset(mt_handle h, int64_t env, const float* points, uint64_t seed, u
   MT_REQUIRE(nullptr, h != nullptr, "handle is NULL");
   MT_REQUIRE(h, env >= 0 && env < h->n, "env index out of range");
   if (!h->is_reset) return fail(h, MT_ERR_STATE, "mt_env_reset before the first reset of the batch");
+  if (points && first_unusable(points, 3 * (int64_t)h->K, kMaxFiniteBits) >= 0)
+    return fail(h, MT_ERR_INVALID_ARG, "mt_env_reset: a target coordinate is NaN or infinite");
   MT_ENTER(h);
   StepArgs a = args_for_env(h, env);
   if (points)  // (K, 3) host floats: flat index 3k + axis = row index
@@ -1440,10 +1482,12 @@ int mt_rollout(mt_handle h, int n_steps, uint64_t seed, uint32_t step_idx0) {
   MT_ON_DEVICE(h, h->cfg.device);  // per-chain call: joins only where it has to (below)
   // several independent chains of launches (env ranges on separate streams) where that pays; a caller who is capturing
   // the handle's stream gets the plain single-stream sequence
-  const int chains = n_steps >= 2 ? usable_chains(h) : 1;
+  int chains = n_steps >= 2 ? usable_chains(h) : 1;
   // Small shards: k steps per launch through the rollout kernels (kPolicy.multi_step_*).  The call exposes the state after
-  // n_steps steps and the outputs of the last one either way; every step still writes its outputs.
+  // n_steps steps and the outputs of the last one either way; every step still writes its outputs.  One chain (see
+  // kPolicy) unless MT_CHAINS asks for more.
   if (h->multi_k > 1 && n_steps >= 2 && fusable(h)) {
+    if (!h->chains_forced) chains = 1;
     StepArgs a = h->args;
     a.seed_lo = (uint32_t)seed;
     a.seed_hi = (uint32_t)(seed >> 32);
@@ -1459,7 +1503,7 @@ int mt_rollout(mt_handle h, int n_steps, uint64_t seed, uint32_t step_idx0) {
           const int64_t off = (int64_t)c * span;
           if (off >= h->n) continue;
           h->stream = c == 0 ? root : h->chain_streams[c];
-          launch_rollout(h, args_for_range(h, a, off, std::min(span, h->n - off)), h->chain_rollout_split, r);
+          launch_rollout(h, args_for_range(h, a, off, std::min(span, h->n - off)), h->chain_rollout_split, r, h->rollout_early);
         }
       }
       h->stream = root;
@@ -1471,7 +1515,7 @@ int mt_rollout(mt_handle h, int n_steps, uint64_t seed, uint32_t step_idx0) {
       if (rc) return rc;
       for (int s0 = 0; s0 < n_steps; s0 += h->multi_k) {
         const RolloutArgs r{std::min(h->multi_k, n_steps - s0), step_idx0 + (uint32_t)s0, 0u, h->cfg.radius};
-        launch_rollout(h, a, h->rollout_split, r);
+        launch_rollout(h, a, h->rollout_split, r, h->rollout_early);
       }
       rc = check_launch(h, "rollout_kernel (mt_rollout)");
     }
@@ -1932,6 +1976,8 @@ int mt_fk_batch(int device, const float* dh_table, int dof, int mode, const floa
   MT_REQUIRE(nullptr, dh_table && angles && out_mat16, "NULL argument");
   MT_REQUIRE(nullptr, dof >= 1 && dof <= MT_MAX_DOF && mode >= 0 && mode <= dof, "dof/mode out of range");
   MT_REQUIRE(nullptr, n >= 1, "n must be >= 1");
+  MT_REQUIRE(nullptr, first_unusable(dh_table, (int64_t)dof * 4, kMaxFiniteBits) < 0 && first_unusable(angles, n * dof, kMaxFiniteBits) < 0,
+             "mt_fk_batch: NaN or infinity in dh_table / angles");
   MT_ON_DEVICE(nullptr, device);
   std::lock_guard<std::mutex> lock(g_scratch_mu);
   const size_t in_b = align_up((size_t)n * dof * 4, 256);
@@ -1956,6 +2002,9 @@ int mt_route_trace(int device, const float* dh_table, int dof, int substeps, con
   MT_REQUIRE(nullptr, dh_table && prev && action && out, "NULL argument");
   MT_REQUIRE(nullptr, dof >= 2 && dof <= MT_MAX_DOF && substeps >= 2, "dof/substeps out of range");
   MT_REQUIRE(nullptr, n >= 1 && n * substeps < ((int64_t)1 << 31), "n out of range");
+  MT_REQUIRE(nullptr, first_unusable(dh_table, (int64_t)dof * 4, kMaxFiniteBits) < 0 && first_unusable(prev, n * dof, kMaxFiniteBits) < 0 &&
+                          first_unusable(action, n * dof, kMaxFiniteBits) < 0,
+             "mt_route_trace: NaN or infinity in dh_table / prev / action");
   MT_ON_DEVICE(nullptr, device);
   const size_t in_b = align_up((size_t)n * dof * 4, 256), out_b = (size_t)n * substeps * dof * 3 * 4;
   std::lock_guard<std::mutex> lock(g_scratch_mu);
@@ -1978,6 +2027,8 @@ int mt_route_trace(int device, const float* dh_table, int dof, int substeps, con
 int mt_r_theta_batch(int device, const float* v1, const float* v2, int64_t n, float* out_r_theta) {
   MT_REQUIRE(nullptr, v1 && v2 && out_r_theta, "NULL argument");
   MT_REQUIRE(nullptr, n >= 1, "n must be >= 1");
+  MT_REQUIRE(nullptr, first_unusable(v1, 3 * n, kMaxFiniteBits) < 0 && first_unusable(v2, 3 * n, kMaxFiniteBits) < 0,
+             "mt_r_theta_batch: NaN or infinity in v1 / v2");
   MT_ON_DEVICE(nullptr, device);
   std::lock_guard<std::mutex> lock(g_scratch_mu);
   void* base = nullptr;

@@ -83,10 +83,12 @@ struct mt_engine {
   // call and -- on the handle's own stream -- left forked across calls (see `forked` below): only the MT_ENTER calls and
   // mt_sync join them; mt_device_ptr does not.
   int chains = 1;
+  bool chains_forced = false;   // MT_CHAINS was given (the multi-step mt_rollout then runs per chain as well)
   int chain_split = 0;          // the step-kernel schedule of a chain's launches is picked for the CHAIN's env count
   bool chain_prefetch = false;
   int chain_rollout_split = 0;  // ... and the rollout-kernel schedule of a chain's multi-step launches
   int multi_k = 1;              // mt_rollout: steps per launch on small shards (rollout kernels), 1 = one launch per step
+  bool rollout_early = true;    // ... with the rollout kernels' RPF prologue (first step under the state loads; static tables)
   std::string overrides;        // the MT_* overrides choose_dispatch saw ("NAME=value,...")
   std::string describe;         // mt_describe_dispatch's text
   hipStream_t chain_streams[kMaxChains] = {nullptr, nullptr, nullptr, nullptr};  // [0] unused: chain 0 runs on `stream`

@@ -1308,7 +1308,24 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(const StepArgs a, float r
     a.total_reward[i] = 0.f;
     a.reward[i] = 0;
     a.done[i] = 0;
-    a.alive[i] = (a.K >= 32) ? 0xFFFFFFFFu : ((1u << a.K) - 1u);
+    uint32_t all_alive = (a.K >= 32) ? 0xFFFFFFFFu : ((1u << a.K) - 1u);
+    if (!RANDOM) {
+      // Targets the caller placed (mt_reset; from device memory they cannot be screened on the host): one with a NaN or an
+      // infinite coordinate is dropped -- dead from the start, coordinates zeroed, counted with the unusable actions -- instead
+      // of reaching arithmetic that is built with -ffinite-math-only.  Tested on the bit pattern.
+      for (int k = 0; k < a.K; ++k) {
+        float* row = a.points + (int64_t)(3 * k) * ld;
+        const uint32_t bx = __float_as_uint(row[i]), by = __float_as_uint((row + ld)[i]), bz = __float_as_uint((row + 2 * ld)[i]);
+        if (((bx & 0x7FFFFFFFu) > 0x7F7FFFFFu) | ((by & 0x7FFFFFFFu) > 0x7F7FFFFFu) | ((bz & 0x7FFFFFFFu) > 0x7F7FFFFFu)) {
+          row[i] = 0.f;
+          (row + ld)[i] = 0.f;
+          (row + 2 * ld)[i] = 0.f;
+          all_alive &= ~(1u << k);
+          atomicAdd(a.bad_actions, 1u);
+        }
+      }
+    }
+    a.alive[i] = all_alive;
     // full reset: the caller names the episode; re-arm of a finished env: its own counter advances by one
     if (ONLY_DONE) episode = a.episodes[i] + 1u;
     a.episodes[i] = episode;
@@ -1444,21 +1461,32 @@ struct RolloutArgs {
   float radius;
 };
 
-template <class Tbl>
+//   RPF : prologue form.  0: the state and all targets are loaded (targets straight into LDS) before the first step starts
+//         -- a launch's first step then waits for the table load, the barrier and every state load in turn before its
+//         Philox block even begins (~6 us before the first step's outputs at 131 072 envs, tools/rollout_k_sweep.py), which
+//         nothing amortises when mt_rollout runs only a few steps per launch.  RPF = kPrefetch: everything is REQUESTED at
+//         the top (table, pose, alive mask, return, the first RPF targets into registers), the first step's Philox block and
+//         kinematics run under those loads, and the targets go to LDS between the first step's kinematics and its target
+//         loop (step 0 is peeled).  Same device functions on the same inputs: the same bits.  The host takes RPF for the
+//         short launches of mt_rollout (engine.hip), the long fused launches keep RPF = 0 (24 fewer live registers).
+template <class Tbl, int RPF = 0>
 __global__ __launch_bounds__(kBlock) void rollout_kernel(const StepArgs a, const RolloutArgs r) {
   extern __shared__ __attribute__((aligned(16))) float tile[];  // [3K][kBlock] (+ the action sin / cos table for the compile-time tables)
   constexpr int D = Tbl::D;
   constexpr bool kTable = ActionTrigTable<Tbl>::value;
   const Tbl t = TableMaker<Tbl>::make(a.dh);
   const SinCos* trig = nullptr;
+  float4 trig_v;
   if constexpr (kTable) {
-    SinCos* w = reinterpret_cast<SinCos*>(tile + 3 * a.K * kBlock);
-    trig_table_commit(w, trig_table_load(a.trig_table));
-    trig = w;
+    trig = reinterpret_cast<const SinCos*>(tile + 3 * a.K * kBlock);
+    trig_v = trig_table_load(a.trig_table);
+    if (!RPF) trig_table_commit(reinterpret_cast<SinCos*>(tile + 3 * a.K * kBlock), trig_v);
   }
   const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
   LaneOffset<true> o4{i * 4u}, o1{i};
-  if (i >= a.n) return;  // no barrier below: every thread touches only its own LDS column
+  // (threads past the end: with a table and RPF they stay until the barrier -- their loads stay inside the rows, which are
+  // ld >= round_up(n, 256) long, and the launch covers the batch or a 256-aligned range of it -- and leave right behind it)
+  if (!(kTable && RPF) && i >= a.n) return;
   const int64_t ld = a.ld;
   const uint64_t seed = ((uint64_t)a.seed_hi << 32) | a.seed_lo;
   const uint64_t env_id = (uint64_t)(a.env_base + i);
@@ -1471,17 +1499,23 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(const StepArgs a, const
   float total = ldr(a.total_reward, o4);
   uint32_t episode = r.auto_reset ? ldr(a.episodes, o4) : 0u;
   bool ended = false, dirty = false;
-  for (int k = 0; k < 3 * a.K; ++k) col[k * kBlock] = ldr(a.points + (int64_t)k * ld, o4);
+  float tx[RPF ? RPF : 1][3];
+  if (RPF) {
+#pragma unroll
+    for (int k = 0; k < RPF; ++k)
+      if (k < a.K) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) tx[k][q] = ldr(a.points + (int64_t)(3 * k + q) * ld, o4);
+      }
+  } else {
+    for (int k = 0; k < 3 * a.K; ++k) col[k * kBlock] = ldr(a.points + (int64_t)k * ld, o4);
+  }
   const uint32_t all_alive = (a.K >= 32) ? 0xFFFFFFFFu : ((1u << a.K) - 1u);
   PoseCache<D> pose;        // sines / cosines and frame heights of the pose the next step starts from
   bool pose_valid = false;  // nothing known about the pose loaded from memory
 
-  for (int s = 0; s < r.T; ++s) {
-    float act[D], el[3], e[3];
-    draw_action<D>(seed, env_id, r.step0 + (uint32_t)s, act);
-    const float zmin = route_kinematics<Tbl, 0, true, kTable>(t, a.S, a.inv_sm1, g, act, el, e, &pose, pose_valid, trig,
-                                                              (a.flags & kFlagWholeGoals) != 0 || s > 0);
-    pose_valid = true;
+  // one step behind its kinematics: observation / pickup per target, outputs, re-arm (the body of the loop below)
+  auto finish_step = [&](const float (&act)[D], const float (&el)[3], const float (&e)[3], float zmin) {
     const bool ground = zmin < 0.f;
     if (a.zmin) str_stream(a.zmin, o4, zmin);  // MT_FLAG_DEBUG_ZMIN (a step output like reward: the last step's stays)
 
@@ -1537,6 +1571,37 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(const StepArgs a, const
       });
       dirty = true;
     }
+  };
+
+  int s = 0;
+  if (RPF) {  // step 0, peeled: its Philox block and kinematics run under the loads requested above
+    float act[D], el[3], e[3];
+    draw_action<D>(seed, env_id, r.step0, act);
+    if constexpr (kTable) {
+      complete_before_here(act);
+      trig_table_commit(reinterpret_cast<SinCos*>(tile + 3 * a.K * kBlock), trig_v);
+      if (i >= a.n) return;
+    }
+    const float zmin = route_kinematics<Tbl, 0, true, kTable>(t, a.S, a.inv_sm1, g, act, el, e, &pose, false, trig,
+                                                              (a.flags & kFlagWholeGoals) != 0);
+    pose_valid = true;
+#pragma unroll
+    for (int k = 0; k < RPF; ++k)
+      if (k < a.K) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) col[(3 * k + q) * kBlock] = tx[k][q];
+      }
+    for (int k = 3 * RPF; k < 3 * a.K; ++k) col[k * kBlock] = ldr(a.points + (int64_t)k * ld, o4);
+    finish_step(act, el, e, zmin);
+    s = 1;
+  }
+  for (; s < r.T; ++s) {
+    float act[D], el[3], e[3];
+    draw_action<D>(seed, env_id, r.step0 + (uint32_t)s, act);
+    const float zmin = route_kinematics<Tbl, 0, true, kTable>(t, a.S, a.inv_sm1, g, act, el, e, &pose, pose_valid, trig,
+                                                              (a.flags & kFlagWholeGoals) != 0 || s > 0);
+    pose_valid = true;
+    finish_step(act, el, e, zmin);
   }
 
 #pragma unroll
@@ -1554,26 +1619,33 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(const StepArgs a, const
 // alive mask, so they stay equal); the targets live in LDS, one column per ENV ([3K][kBlock / L]), written by whichever
 // sub-lane owns the target.  A wave only ever touches its own columns: wave_barrier() orders the LDS traffic, no
 // block barrier.  Bit-identical to rollout_kernel.
-template <class Tbl, int L>
+template <class Tbl, int L, int RPF = 0>
 __global__ __launch_bounds__(kBlock) void rollout_split_kernel(const StepArgs a, const RolloutArgs r) {
   static_assert(L == 2 || L == 4, "an env is spread over 2 or 4 lanes");
   extern __shared__ __attribute__((aligned(16))) float tile[];  // [3K][kBlock / L] (+ the action sin / cos table for the compile-time tables)
   constexpr int D = Tbl::D;
   constexpr int EPW = 64 / L;
   constexpr int EPB = kBlock / L;  // envs per block = columns of the tile
+  constexpr int PFS = (RPF + L - 1) / L;  // targets per sub-lane requested up front (RPF form, see rollout_kernel)
   constexpr bool kTable = ActionTrigTable<Tbl>::value;
   const Tbl t = TableMaker<Tbl>::make(a.dh);
   const SinCos* trig = nullptr;
+  float4 trig_v;
   if constexpr (kTable) {
-    SinCos* w = reinterpret_cast<SinCos*>(tile + 3 * a.K * EPB);
-    trig_table_commit(w, trig_table_load(a.trig_table));
-    trig = w;
+    trig = reinterpret_cast<const SinCos*>(tile + 3 * a.K * EPB);
+    trig_v = trig_table_load(a.trig_table);
+    if (!RPF) trig_table_commit(reinterpret_cast<SinCos*>(tile + 3 * a.K * EPB), trig_v);
   }
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
   const uint32_t q = lane / EPW;
   const int64_t first = (int64_t)wave * EPW;
-  if (first >= a.n) return;
+  if (first >= a.n) {  // whole wave beyond the batch
+    if constexpr (kTable) {
+      if (RPF) trig_table_commit(reinterpret_cast<SinCos*>(tile + 3 * a.K * EPB), trig_v);  // its arrival at the block's barrier
+    }
+    return;
+  }
   const uint32_t env = (uint32_t)first + lane % EPW;
   const bool live = env < a.n;  // tail lanes work on a copy of the last env (in their own column) and store nothing
   const uint32_t i = live ? env : (uint32_t)(a.n - 1);
@@ -1590,21 +1662,29 @@ __global__ __launch_bounds__(kBlock) void rollout_split_kernel(const StepArgs a,
   float total = a.total_reward[i];
   uint32_t episode = r.auto_reset ? a.episodes[i] : 0u;
   bool ended = false, dirty = false;
-  for (int p = (int)q; p < a.K; p += L) {  // this sub-lane's targets into the env's column
-    const float* row = a.points + (int64_t)(3 * p) * ld;
+  float tx[PFS ? PFS : 1][3];
+  if (RPF) {  // this sub-lane's first targets into registers (target index p = q + L * m)
 #pragma unroll
-    for (int c = 0; c < 3; ++c) col[(3 * p + c) * EPB] = (row + c * ld)[i];
+    for (int m = 0; m < PFS; ++m) {
+      const int p = (int)q + L * m;
+      if (p < a.K) {
+        const float* row = a.points + (int64_t)(3 * p) * ld;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) tx[m][c] = (row + c * ld)[i];
+      }
+    }
+  } else {
+    for (int p = (int)q; p < a.K; p += L) {  // this sub-lane's targets into the env's column
+      const float* row = a.points + (int64_t)(3 * p) * ld;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) col[(3 * p + c) * EPB] = (row + c * ld)[i];
+    }
   }
   const uint32_t all_alive = (a.K >= 32) ? 0xFFFFFFFFu : ((1u << a.K) - 1u);
   PoseCache<D> pose;
   bool pose_valid = false;
 
-  for (int s = 0; s < r.T; ++s) {
-    float act[D], el[3], e[3];
-    draw_action<D>(seed, env_id, r.step0 + (uint32_t)s, act);
-    const float zmin = route_kinematics_split<Tbl, L, true, kTable>(t, a.S, a.inv_sm1, g, act, backward, el, e, &pose, pose_valid,
-                                                                    trig, (a.flags & kFlagWholeGoals) != 0 || s > 0);
-    pose_valid = true;
+  auto finish_step = [&](const float (&act)[D], const float (&el)[3], const float (&e)[3], float zmin) {
     const bool ground = zmin < 0.f;
     if (a.zmin && live && q == 0) __builtin_nontemporal_store(zmin, a.zmin + i);  // MT_FLAG_DEBUG_ZMIN
 
@@ -1672,6 +1752,42 @@ __global__ __launch_bounds__(kBlock) void rollout_split_kernel(const StepArgs a,
       });
       dirty = true;
     }
+  };
+
+  int s = 0;
+  if (RPF) {  // step 0, peeled: its Philox block and kinematics run under the loads requested above
+    float act[D], el[3], e[3];
+    draw_action<D>(seed, env_id, r.step0, act);
+    if constexpr (kTable) {
+      complete_before_here(act);
+      trig_table_commit(reinterpret_cast<SinCos*>(tile + 3 * a.K * EPB), trig_v);
+    }
+    const float zmin = route_kinematics_split<Tbl, L, true, kTable>(t, a.S, a.inv_sm1, g, act, backward, el, e, &pose, false, trig,
+                                                                    (a.flags & kFlagWholeGoals) != 0);
+    pose_valid = true;
+#pragma unroll
+    for (int m = 0; m < PFS; ++m) {
+      const int p = (int)q + L * m;
+      if (p < a.K) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) col[(3 * p + c) * EPB] = tx[m][c];
+      }
+    }
+    for (int p = (int)q + L * PFS; p < a.K; p += L) {
+      const float* row = a.points + (int64_t)(3 * p) * ld;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) col[(3 * p + c) * EPB] = (row + c * ld)[i];
+    }
+    finish_step(act, el, e, zmin);
+    s = 1;
+  }
+  for (; s < r.T; ++s) {
+    float act[D], el[3], e[3];
+    draw_action<D>(seed, env_id, r.step0 + (uint32_t)s, act);
+    const float zmin = route_kinematics_split<Tbl, L, true, kTable>(t, a.S, a.inv_sm1, g, act, backward, el, e, &pose, pose_valid,
+                                                                    trig, (a.flags & kFlagWholeGoals) != 0 || s > 0);
+    pose_valid = true;
+    finish_step(act, el, e, zmin);
   }
 
   if (live && q == 0) {

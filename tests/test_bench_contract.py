@@ -18,7 +18,7 @@ def test_bench_prints_one_contract_line():
     assert out.stdout.count("\n") == 1 and out.stdout.endswith("\n")     # nothing but the line (native chatter -> stderr)
     d = json.loads(out.stdout)
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "value_device_timeline", "device_ms_per_step"):
         assert key in d, key
     assert d["metric"] == "env-steps/sec (whole node), 1M parallel 4-DoF arms, random actions"
     assert d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 5 and d["higher_is_better"] is True
@@ -29,18 +29,27 @@ def test_bench_prints_one_contract_line():
     assert d["value"] == pytest.approx(262144 / (d["ms_per_step"] * 1e-3), rel=1e-6)
     r = d["roofline"]
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "bytes_per_env_step", "avg_kernel_us",
-                "frac_survey_model", "regime"):
+                "frac_survey_model", "regime", "achievable_gbs", "achievable_gbs_same_size", "steps_per_kernel_launch"):
         assert key in r, key
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert r["frac"] == pytest.approx(r["achieved"] / r["peak"]) and 0.05 < r["frac"] < 1.0
-    # achieved = the bytes the timed kernel really moves (SURVEY's 249 B minus the 16 B action read it does not do) per
-    # step / the device time of one step; SURVEY's own figure beside it
-    assert r["bytes_per_env_step"] == 233 and r["bytes_per_env_step_survey_model"] == 249
-    assert r["achieved"] == pytest.approx(233 * 262144 / (r["avg_kernel_us"] * 1e-6) / 1e9, rel=1e-6)
-    assert r["frac_survey_model"] == pytest.approx(r["frac"] * 249 / 233, rel=1e-6)
+    # 262 144 arms: mt_rollout runs five steps per launch there (one chain), so a step moves its outputs (12 K + 17 B) and a
+    # fifth of the state traffic (8 D + 12 K + 16 B per launch): achieved = those bytes / the device time of one step;
+    # SURVEY's own 249-byte figure beside it
+    assert r["steps_per_kernel_launch"] == 5.0 and r["launches_per_step"] == 1 and r["envs_per_launch"] == 262144
+    assert d["config"]["dispatch"]["rollout"] == {"form": "multi_step", "steps_per_launch": 5, "graph": False, "lanes_per_env": 1, "chains": 1}
+    assert "5 steps per launch" in r["kernel"]
+    moved = 101 + 132 / 5
+    assert r["bytes_per_env_step"] == pytest.approx(moved) and r["bytes_per_env_step_survey_model"] == 249
+    assert r["achieved"] == pytest.approx(moved * 262144 / (r["avg_kernel_us"] * 1e-6) / 1e9, rel=1e-6)
+    assert r["frac_survey_model"] == pytest.approx(r["frac"] * 249 / moved, rel=1e-6)
     assert r["avg_kernel_us"] * 1e-3 <= d["ms_per_step"]                 # the step's device time fits inside the wall-clock step
-    assert r["launches_per_step"] == 2 and r["envs_per_launch"] == 131072 and "2 chains of 131072 envs" in r["kernel"]
-    assert r["bytes_per_step"] == 233 * 262144 and r["bytes_per_launch"] * r["launches_per_step"] == r["bytes_per_step"]
+    assert r["bytes_per_step"] == pytest.approx(moved * 262144)
+    assert r["bytes_per_launch"] == pytest.approx(moved * 5 * 262144)
+    # the region on the device's clock: between the step launches alone and the fenced wall clock
+    assert r["avg_kernel_us"] * 1e-3 <= d["device_ms_per_step"] <= d["ms_per_step"]
+    assert d["value_device_timeline"] == pytest.approx(262144 / (d["device_ms_per_step"] * 1e-3), rel=1e-6)
+    assert r["achievable_gbs"] > 2000 and r["achievable_gbs_same_size"] > 2000
     c = d["cpu_baseline"]
     for key in ("value", "unit", "cores", "kind", "sample", "numpy_multiprocess_value", "numpy_multiprocess_cores"):
         assert key in c, key

@@ -714,13 +714,15 @@ DISPATCH_REGIMES = [(32768, "L=4"), (65536, "L=2"), (131072, "pf=8"), (262144, N
 
 @pytest.mark.parametrize("table_name", ["ref", "dh7"])
 @pytest.mark.parametrize("n,expect", DISPATCH_REGIMES)
-def test_full_size_every_env_against_the_c_oracle(m, table_name, n, expect):
+def test_full_size_every_env_against_the_c_oracle(m, monkeypatch, table_name, n, expect):
     """BASELINE.json's sizes (configs[1] = 65 536, configs[2] / [4] = 1 048 576, the 131 072-arm shard of the 1 M strong
     scaling point) and every dispatch regime in between, ALL envs compared (not a sample): the C restatement of the
     reference (oracle/manytor_oracle.c, OpenMP) steps the same targets and actions; positions, observations and --
     outside the guard band -- rewards / alive masks / done flags must agree for every env, three steps in a row, on the
-    kernel mt_create actually selects for that size.  Up to 131 072 arms the same steps are then replayed through
-    mt_rollout's cached HIP graph (second request of a segment length) and must give the same bits."""
+    kernel mt_create actually selects for that size.  Up to 262 144 arms the same steps are then run as ONE mt_rollout
+    segment, requested twice -- the default there is k steps per launch through the rollout kernels (round 4); with
+    MT_ROLLOUT_K=1 it is a launch per step, replayed from the cached HIP graph at the second request up to 131 072 arms --
+    and must give the same bits either way."""
     from oracle import c_oracle
     table = m.REF_DH_TABLE if table_name == "ref" else m.DH7_TABLE
     radius = 51.3 if table_name == "ref" else 92.6
@@ -754,15 +756,21 @@ def test_full_size_every_env_against_the_c_oracle(m, table_name, n, expect):
         ora.points[idx] = eng.points()[idx].astype(np.float64)
         np.testing.assert_array_equal(eng.total_reward(), ora.total_reward.astype(np.float32))
     assert guarded_total < 3 * n * 2e-3 + 8, guarded_total
-    if n <= 131072:
-        # the same three steps as ONE mt_rollout segment, requested twice: the second request replays the cached graph
-        # (not F_LAST_RETURN: a full reset stores the return of the episode it ends)
+    if n <= 262144:
+        # the same three steps as ONE mt_rollout segment, requested twice (not F_LAST_RETURN: a full reset stores the return
+        # of the episode it ends): the default dispatch, then one launch per step (the second request replays the cached graph)
         want = {f: eng.get(getattr(m.lib, f)) for f in STATE_FIELDS + STEP_FIELDS if f != "F_LAST_RETURN"}
-        for attempt in range(2):
-            eng.reset_random(0xC0FFEE, 0)
-            eng.rollout(3, 0xC0FFEE, 0)
-            for f, v in want.items():
-                np.testing.assert_array_equal(eng.get(getattr(m.lib, f)), v, err_msg=f"rollout attempt {attempt}: {f}")
+        assert eng.dispatch()["rollout"]["form"] == "multi_step"
+        monkeypatch.setenv("MT_ROLLOUT_K", "1")
+        per_step = m.StepEngine(n, k, dh_table=table, radius=radius)
+        assert per_step.dispatch()["rollout"]["form"] == ("graph_replay" if n <= 131072 else "chained_steps")
+        for e in (eng, per_step):
+            for attempt in range(2):
+                e.reset_random(0xC0FFEE, 0)
+                e.rollout(3, 0xC0FFEE, 0)
+                for f, v in want.items():
+                    np.testing.assert_array_equal(e.get(getattr(m.lib, f)), v, err_msg=f"rollout attempt {attempt}: {f}")
+        per_step.close()
 
 
 def test_full_size_fused_equals_per_step(m):
@@ -1036,6 +1044,7 @@ def test_rollout_through_a_replayed_graph_equals_plain_launches(m, case, monkeyp
                 "ref_large_forced": (dict(), 300000, 7)}[case]
     fields = ("F_GOALS", "F_ALIVE", "F_TOTAL_REWARD", "F_POINTS", "F_OBS", "F_REWARD", "F_DONE", "F_DONE_BITS", "F_EE")
     outs = []
+    monkeypatch.setenv("MT_ROLLOUT_K", "1")      # one launch per step: the form the graphs exist for (tests/test_gpu_r04.py has k > 1)
     for mode in ("0", "1", None):                                     # None: the library's own choice (graph from the
         if mode is None:                                              # second request of a segment length, small batches)
             monkeypatch.delenv("MT_GRAPH", raising=False)
@@ -1127,6 +1136,7 @@ def test_rollout_in_independent_chains_equals_plain_launches(m, monkeypatch, n, 
     table = m.REF_DH_TABLE if table_name == "ref" else m.DH7_TABLE
     radius = 51.3 if table_name == "ref" else 92.6
     fields = STATE_FIELDS + STEP_FIELDS
+    monkeypatch.setenv("MT_ROLLOUT_K", "1")      # chains of STEP kernels (what batches > 262 144 envs run); k > 1: test_gpu_r04.py
     monkeypatch.setenv("MT_CHAINS", "1")
     monkeypatch.setenv("MT_GRAPH", "0")
     ref = m.StepEngine(n, k, dh_table=table, radius=radius, pickup_tol=20.0)
