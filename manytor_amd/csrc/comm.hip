@@ -253,13 +253,26 @@ static const float* gather_source(mt_handle h, int field, int row, int* rc) {
   return src + (int64_t)row * h->ld;
 }
 
+// The snapshot of a return row as a kernel: a device-to-device hipMemcpyAsync of 0.5-4 MB is a blit kernel between two
+// barriers of the runtime's own (12 us of idle queue ahead of it and 7 behind it in the trace of a 131 072-env shard), a
+// launch of this kernel follows the step kernels like any other launch.
+__global__ __launch_bounds__(kBlock) void row_copy_kernel(float* __restrict__ dst, const float* __restrict__ src, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i < n) dst[i] = src[i];
+}
+static int row_copy(mt_handle h, float* dst, const float* src, int64_t n, hipStream_t stream) {
+  hipLaunchKernelGGL(row_copy_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, dst, src, n);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(h, MT_ERR_HIP, std::string("row_copy_kernel launch: ") + hipGetErrorString(e));
+  return MT_OK;
+}
+
 // The exchange itself: `src` = this rank's n floats (an arena row or its snapshot), on `stream`.
 static int gather_on_stream(mt_handle h, const float* src, float* dst, int64_t dst_elems, hipStream_t stream) {
   mt_comm* c = h->comm;
   if (!c || c->world == 1) {
     MT_REQUIRE(h, dst_elems == h->n, "dst_elems must be the total number of envs");
-    MT_HIP(h, hipMemcpyAsync(dst, src, sizeof(float) * (size_t)h->n, hipMemcpyDeviceToDevice, stream));
-    return MT_OK;
+    return row_copy(h, dst, src, h->n, stream);  // (one rank: the "exchange" is a device copy; as a kernel, see row_copy)
   }
   MT_REQUIRE(h, dst_elems == c->total, "dst_elems must be the total number of envs over all ranks");
   Rccl* r = rccl();
@@ -317,8 +330,14 @@ __global__ __launch_bounds__(kBlock) void reduce_returns_kernel(const float* __r
 }
 
 // A gather begun with mt_gather_returns_begin and not yet waited for: order `stream` behind it.
+// (An exchange that has already FINISHED -- the normal case one episode later -- needs no barrier packet in the queue: the
+// event is asked first.  A stream wait costs a few microseconds of device time even on a signalled event, and the episode
+// end of a 131 072-env shard is ~40 us long: tools/region_timeline.py, profiles/r04_variants.md section 4.)
 static int order_behind_pending_gather(mt_handle h, hipStream_t stream) {
-  if (h->gather_pending) MT_HIP(h, hipStreamWaitEvent(stream, h->ev_g1, 0));
+  if (!h->gather_pending) return MT_OK;
+  if (hipEventQuery(h->ev_g1) == hipSuccess) return MT_OK;
+  (void)hipGetLastError();  // hipErrorNotReady is not an error of ours
+  MT_HIP(h, hipStreamWaitEvent(stream, h->ev_g1, 0));
   return MT_OK;
 }
 
@@ -424,9 +443,9 @@ static int gather_begin_impl(mt_handle h, int field, int row, float* dst, int64_
   }
   if (!h->snap) {  // first use: the side stream, its events, and the snapshot row (`snap` is set last: all or nothing)
     hipError_t e = hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_snap, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventCreate(&h->ev_g0);
-    if (e == hipSuccess) e = hipEventCreate(&h->ev_g1);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_snap, mt::event_flags(false));
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_g0, mt::event_flags(true));
+    if (e == hipSuccess) e = hipEventCreate(&h->ev_g1);  // (default: mt_gather_returns_wait(host) hands dst to the caller behind it)
     if (e == hipSuccess) e = hipMalloc(&h->snap, sizeof(float) * (size_t)h->n);
     if (e != hipSuccess) {
       (void)hipGetLastError();
@@ -449,7 +468,8 @@ static int gather_begin_impl(mt_handle h, int field, int row, float* dst, int64_
         if (rc) return rc;
       }
       const int64_t cnt = std::min(span, h->n - off);
-      MT_HIP(h, hipMemcpyAsync(h->snap + off, src + off, sizeof(float) * (size_t)cnt, hipMemcpyDeviceToDevice, sc));
+      rc = row_copy(h, h->snap + off, src + off, cnt, sc);
+      if (rc) return rc;
       if (c > 0) {
         if (!h->ev_join[c]) return fail(h, MT_ERR_STATE, "mt_gather_returns_begin: chain without its event");
         // (ev_join[c] is free while the chains are forked: a join records it afresh)
@@ -459,7 +479,8 @@ static int gather_begin_impl(mt_handle h, int field, int row, float* dst, int64_
     }
     src = h->snap;
   } else if (!inplace) {
-    MT_HIP(h, hipMemcpyAsync(h->snap, src, sizeof(float) * (size_t)h->n, hipMemcpyDeviceToDevice, h->stream));
+    rc = row_copy(h, h->snap, src, h->n, h->stream);
+    if (rc) return rc;
     src = h->snap;
   }
   MT_HIP(h, hipEventRecord(h->ev_snap, h->stream));
@@ -486,7 +507,10 @@ int mt_gather_returns_wait(mt_handle h, int host_wait, float* elapsed_ms) {
   if (elapsed_ms) *elapsed_ms = host_wait ? h->last_gather_ms : 0.f;  // nothing pending: the last completed exchange
   if (!h->gather_pending) return MT_OK;
   MT_ON_DEVICE(h, h->cfg.device);  // no join: only the handle's own stream is ordered behind the exchange
-  MT_HIP(h, hipStreamWaitEvent(h->stream, h->ev_g1, 0));
+  if (hipEventQuery(h->ev_g1) != hipSuccess) {  // (already finished: no barrier packet needed, see order_behind_pending_gather)
+    (void)hipGetLastError();
+    MT_HIP(h, hipStreamWaitEvent(h->stream, h->ev_g1, 0));
+  }
   if (host_wait) {
     MT_HIP(h, hipEventSynchronize(h->ev_g1));
     MT_HIP(h, hipEventElapsedTime(&h->last_gather_ms, h->ev_g0, h->ev_g1));

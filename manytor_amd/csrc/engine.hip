@@ -464,10 +464,10 @@ void launch_step(mt_handle h, bool sample) { launch_step(h, h->args, h->trace, s
 StepArgs args_for_range(mt_handle h, const StepArgs& base, int64_t off, int64_t cnt);
 int check_launch(mt_handle h, const char* what);
 int ensure_chains(mt_handle h, int chains) {
-  if (!h->ev_fork) MT_HIP(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+  if (!h->ev_fork) MT_HIP(h, hipEventCreateWithFlags(&h->ev_fork, event_flags(false)));
   for (int c = 1; c < chains; ++c) {
     if (!h->chain_streams[c]) MT_HIP(h, hipStreamCreateWithFlags(&h->chain_streams[c], hipStreamNonBlocking));
-    if (!h->ev_join[c]) MT_HIP(h, hipEventCreateWithFlags(&h->ev_join[c], hipEventDisableTiming));
+    if (!h->ev_join[c]) MT_HIP(h, hipEventCreateWithFlags(&h->ev_join[c], event_flags(false)));
   }
   return MT_OK;
 }
@@ -707,8 +707,14 @@ static int order_behind_inplace_gather(mt_handle h, hipStream_t stream) {
 
 // Chains a whole-batch call may run as, right now: the handle's chain count unless the sub-step trace is on or the caller
 // is capturing the handle's stream into a graph of their own (they get the plain single-stream sequence).
-static int usable_chains(mt_handle h) {
+// per_step_call: mt_step / mt_sample_actions / mt_set_actions -- ONE launch per range and call.  On a caller's stream every
+// call has to fork behind the caller's work and join back before it returns, two cross-stream dependencies for one launch:
+// measured with a torch policy on the same stream (examples/policy_loop.py, 1 M arms) 144.4 us per loop iteration in two
+// chains against 127.3 in one (profiles/r04_policy_loop_chains_on_torch_stream.txt), so there the step stays one launch.
+// On the handle's own stream the chains stay forked from call to call and the step is 42.3 -> 37.1 us.
+static int usable_chains(mt_handle h, bool per_step_call = false) {
   if (h->chains <= 1 || h->trace) return 1;
+  if (per_step_call && !(h->lazy_chains && h->stream == h->own_stream)) return 1;
   hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(h->stream, &st) != hipSuccess || st != hipStreamCaptureStatusNone) {
     (void)hipGetLastError();
@@ -831,8 +837,8 @@ int mt_create(mt_handle* out, const mt_config* cfg) {
   if (guard.error() != hipSuccess) return bail(MT_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(guard.error()));
   MT_HIP_C(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
   h->stream = h->own_stream;
-  MT_HIP_C(hipEventCreate(&h->ev0));
-  MT_HIP_C(hipEventCreate(&h->ev1));
+  MT_HIP_C(hipEventCreateWithFlags(&h->ev0, event_flags(true)));
+  MT_HIP_C(hipEventCreateWithFlags(&h->ev1, event_flags(true)));
 
   // arena layout: every row block starts on a 1 KiB boundary
   const size_t ld = (size_t)h->ld, D = (size_t)h->D, K = (size_t)h->K;
@@ -1145,7 +1151,7 @@ int mt_set_actions(mt_handle h, const void* actions, int dtype, int layout, int 
   const size_t es = (dtype == MT_F32 || dtype == MT_I32) ? 4 : 8;
   // Device sources of a multi-chain handle are staged per chain -- each range's rows on its chain's stream, right ahead of
   // that range's mt_step -- so that a policy loop (mt_set_actions(device) / mt_step, ...) keeps the chains forked.
-  const int chains = is_device ? usable_chains(h) : 1;
+  const int chains = is_device ? usable_chains(h, true) : 1;
   if (chains > 1) {
     MT_ON_DEVICE(h, h->cfg.device);
     const int D = h->D;
@@ -1218,7 +1224,7 @@ int mt_set_actions(mt_handle h, const void* actions, int dtype, int layout, int 
 
 int mt_sample_actions(mt_handle h, uint64_t seed, uint32_t step_idx) {
   MT_REQUIRE(nullptr, h != nullptr, "handle is NULL");
-  const int chains = usable_chains(h);
+  const int chains = usable_chains(h, true);
   if (chains > 1) {  // per chain: each range's actions are written on its chain's stream, ahead of that range's mt_step
     MT_ON_DEVICE(h, h->cfg.device);
     return per_chain(h, chains, "sample_actions_kernel (per chain)", [&](int, int64_t off, int64_t cnt) {
@@ -1239,8 +1245,8 @@ int mt_step(mt_handle h) {
   // The policy-in-the-loop step: on a multi-chain handle each half of the env range is one launch on its own stream, as in
   // mt_rollout (a step of env i depends only on env i: same bits, one half's kernel boundary behind the other's kernel).
   // On the handle's own stream the chains stay forked across mt_set_actions(device) / mt_sample_actions / mt_step calls;
-  // on a caller's stream (a torch policy on the same stream) every call forks behind the caller's work and joins back.
-  const int chains = usable_chains(h);
+  // on a caller's stream (a torch policy on the same stream) the step is one launch (see usable_chains).
+  const int chains = usable_chains(h, true);
   if (chains > 1) {
     MT_ON_DEVICE(h, h->cfg.device);
     const StepArgs a = h->args;
@@ -1813,7 +1819,7 @@ int mt_timer_stop_async(mt_handle h) {
   if (h->forked)
     for (int c = 1; c < h->chains; ++c) {
       if (!h->chain_streams[c] || (int64_t)c * chain_span(h, h->chains) >= h->n) continue;
-      if (!h->ev1c[c]) MT_HIP(h, hipEventCreate(&h->ev1c[c]));
+      if (!h->ev1c[c]) MT_HIP(h, hipEventCreateWithFlags(&h->ev1c[c], event_flags(true)));
       MT_HIP(h, hipEventRecord(h->ev1c[c], h->chain_streams[c]));
       h->timer_ends = c + 1;
     }
@@ -1851,7 +1857,7 @@ int mt_timer_read(mt_handle h, float* elapsed_ms) {
 static int lap_event(mt_handle h, hipStream_t stream, uint32_t* index) {
   if (h->lap_events_used == h->lap_events.size()) {
     hipEvent_t e = nullptr;
-    MT_HIP(h, hipEventCreate(&e));
+    MT_HIP(h, hipEventCreateWithFlags(&e, event_flags(true)));
     h->lap_events.push_back(e);
   }
   MT_HIP(h, hipEventRecord(h->lap_events[h->lap_events_used], stream));

@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -106,6 +107,20 @@ struct mt_engine {
 };
 
 namespace mt {
+
+// Event flags.  A default HIP event performs a SYSTEM-scope release when it is recorded (cache write-back so that the host
+// may inspect what ran before it): between two launches of a stream that is a bubble of 7-12 us (tools/episode_end_cost.py,
+// profiles/r04_variants.md section 4: the overlapped gather's one event record cost the episode end of a 131 072-env
+// shard 18 us).  The events this library records only order streams of ONE device against each other, or only time them;
+// the launches themselves carry the device-scope fences that make a kernel's writes visible to the next one.  MT_EVENT_FENCE
+// = 1 gives the default events back (A/B, tools/episode_end_cost.py).
+inline unsigned event_flags(bool timing) {
+  static const bool fenced = [] {
+    const char* e = std::getenv("MT_EVENT_FENCE");
+    return e && *e && std::atoi(e) != 0;
+  }();
+  return (timing ? 0u : (unsigned)hipEventDisableTiming) | (fenced ? 0u : (unsigned)hipEventDisableSystemFence);
+}
 
 // Records `msg` where mt_last_error will find it (on the handle, or per thread when there is none).
 int fail(mt_handle h, int code, const std::string& msg);

@@ -45,11 +45,13 @@ def record_clean(*row):
     try:
         os.makedirs(os.path.dirname(path), exist_ok=True)
         with open(path, "a") as f:
-            f.write(json.dumps(dict(zip(("table", "n", "k", "T", "auto_reset", "tol", "clean"), row))) + "\n")
+            f.write(json.dumps(dict(zip(("table", "n", "k", "T", "auto_reset", "tol", "clean", "touching_env_steps",
+                                         "env_steps_behind_a_touch"), row))) + "\n")
     except OSError:
         pass
     print(f"[fused-vs-oracle] {row[0]} n={row[1]} K={row[2]} T={row[3]} auto_reset={row[4]} tol={row[5]}: "
-          f"clean fraction {row[6]:.4f}")
+          f"clean fraction {row[6]:.4f}, env-steps inside the guard band {row[7]:.5f}, env-steps behind an env's first touch "
+          f"(EE check only) {row[8]:.4f}")
 
 
 def run_fused_against_oracle(m, n, k, table_name, T, auto_reset, tol, seed, min_clean):
@@ -65,6 +67,8 @@ def run_fused_against_oracle(m, n, k, table_name, T, auto_reset, tol, seed, min_
     eng.rollout_fused(T, seed, 0, auto_reset=auto_reset)          # ONE launch on the GPU
 
     clean = np.ones(n, dtype=bool)
+    touches = 0                                                    # env-steps whose own decision sat inside the guard band
+    behind = 0                                                     # env-steps of envs that had touched it before (or just did)
     episodes = np.zeros(n, dtype=np.int64)
     last_ret = np.zeros(n)
     ring = np.zeros((n, RING))
@@ -74,7 +78,10 @@ def run_fused_against_oracle(m, n, k, table_name, T, auto_reset, tol, seed, min_
         pre_alive = ora.alives.copy()
         obs_ref, rew_ref, done_ref = ora.step(act)
         pm = np.where(pre_alive, ora.pickup_margin, np.inf).min(axis=1)
-        clean &= ~((ora.ground_margin < GUARD) | (pm < GUARD))
+        risky = (ora.ground_margin < GUARD) | (pm < GUARD)
+        touches += int(risky.sum())
+        clean &= ~risky
+        behind += int((~clean).sum())
         if t == T - 1:
             last = dict(obs=obs_ref, rew=rew_ref, done=done_ref, jc=ora.joints_coordinates.copy(), pre_alive=pre_alive,
                         points=ora.points.copy())
@@ -89,7 +96,7 @@ def run_fused_against_oracle(m, n, k, table_name, T, auto_reset, tol, seed, min_
             ora.points[idx] = px.sample_targets(seed, ids[idx], episodes[idx], k, radius).astype(np.float64)
 
     c = clean
-    record_clean(table_name, n, k, T, auto_reset, tol, float(c.mean()))
+    record_clean(table_name, n, k, T, auto_reset, tol, float(c.mean()), touches / (n * T), behind / (n * T))
     assert c.mean() >= min_clean, c.mean()
     # state after the rollout
     np.testing.assert_array_equal(eng.goals()[c], ora.goals[c].astype(np.float32))

@@ -17,7 +17,7 @@ summary = {k: {c: {"avg": sum(v) / len(v), "n": len(v)} for c, v in cs.items()} 
 with open(os.path.join(out, "pmc_summary.json"), "w") as f:
     json.dump(summary, f, indent=1, sort_keys=True)
 for k, cs in summary.items():
-    if "step_kernel" in k:
+    if "step_kernel" in k or "rollout" in k or "stream_probe" in k:
         print(k)
         for c, v in sorted(cs.items()):
             print(f"   {c:24s} {v['avg']:.6g}  (n={v['n']})")

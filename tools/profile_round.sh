@@ -14,4 +14,5 @@ python3 tools/trace_summary.py "$trace_csv" --union "step_kernel<mt::Ref4Table, 
 tail -1 "$out/kernel_stats_by_grid.csv"
 bash tools/pmc_step.sh "$out/pmc_d4" --no-secondary > "$out/pmc_d4.log" 2>&1 || echo "pmc d4 failed"
 bash tools/pmc_step.sh "$out/pmc_d7" --no-secondary --dof 7 > "$out/pmc_d7.log" 2>&1 || echo "pmc d7 failed"
-tail -12 "$out/pmc_d4.log"; tail -12 "$out/pmc_d7.log"
+bash tools/pmc_step.sh "$out/pmc_131072" --no-secondary --envs-per-gpu 131072 > "$out/pmc_131072.log" 2>&1 || echo "pmc 131072 failed"
+tail -12 "$out/pmc_d4.log"; tail -12 "$out/pmc_d7.log"; tail -24 "$out/pmc_131072.log"

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Timeline of the kernels around an episode boundary of bench.py's headline run, from a rocprofv3 --kernel-trace CSV:
 start / end (us, relative to a reset of the 1 M-arm batch in the middle of the run), duration, queue, grid, kernel.
-    python tools/region_timeline.py <kernel_trace.csv> [rows]"""
+    python tools/region_timeline.py <kernel_trace.csv> [rows] [min grid of the reset to centre on, default 262144]"""
 import csv
 import sys
 
@@ -10,7 +10,8 @@ for r in csv.DictReader(open(sys.argv[1])):
     n = r["Kernel_Name"]
     rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), n.split("(")[0][-44:], int(r["Grid_Size_X"]), r.get("Queue_Id", "?")))
 rows.sort()
-resets = [i for i, r in enumerate(rows) if "reset_kernel" in r[2] and r[3] >= 262144]
+min_grid = int(sys.argv[3]) if len(sys.argv) > 3 else 262144
+resets = [i for i, r in enumerate(rows) if "reset" in r[2] and "kernel" in r[2] and r[3] >= min_grid]
 j = resets[len(resets) // 2]
 base = rows[j][0]
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 60
