@@ -208,15 +208,19 @@ def achievable_bandwidth(m, dof, k, n_envs, dev, reps=0):
     return nbytes / (us * 1e-6) / 1e9
 
 
-def load_traffic(workload_key):
+def load_traffic(workload_key, steps_per_launch=1.0):
     """HBM bytes per step launch from the committed PMC run (profiles/traffic.json), or None.  PMC counters need
-    their own rocprofv3 passes, so this figure cannot be taken inside a bench run; `traffic_source` says so."""
+    their own rocprofv3 passes, so this figure cannot be taken inside a bench run; `traffic_source` says so.  An entry
+    measured with k steps per launch only answers for a run that launches the same way."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         with open(path) as f:
-            return json.load(f).get(workload_key, {}).get("hbm_bytes_per_launch")
+            entry = json.load(f).get(workload_key, {})
     except (OSError, ValueError):
         return None
+    if round(float(entry.get("steps_per_launch", 1))) != round(float(steps_per_launch)):
+        return None
+    return entry.get("hbm_bytes_per_launch")
 
 
 class EpisodeLoop:
@@ -889,9 +893,11 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": load_traffic(f"d{args.dof}_k{args.targets}_n{n_local}") if spl == 1 else None,
+                "traffic": load_traffic(f"d{args.dof}_k{args.targets}_n{n_local}", spl),
                 "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, committed under "
-                                  "profiles/ (traffic.json); not re-measured in this run",
+                                  "profiles/ (traffic.json); not re-measured in this run.  Per STEP where a step is one or two "
+                                  "launches (bytes_per_step is its counterpart), per LAUNCH of steps_per_kernel_launch steps "
+                                  "where mt_rollout runs several steps per launch (counterpart: bytes_per_launch)",
                 "kernel": (f"rollout_kernel<{table_name}> ({L} steps per launch; us per step quoted)" if args.fused else
                            kernel_name + " (action drawn in-kernel)"),
                 "bytes_per_env_step": moved, "avg_kernel_us": r["step_us"], "steps_timed": r["launches"],

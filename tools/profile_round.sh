@@ -16,3 +16,7 @@ bash tools/pmc_step.sh "$out/pmc_d4" --no-secondary > "$out/pmc_d4.log" 2>&1 || 
 bash tools/pmc_step.sh "$out/pmc_d7" --no-secondary --dof 7 > "$out/pmc_d7.log" 2>&1 || echo "pmc d7 failed"
 bash tools/pmc_step.sh "$out/pmc_131072" --no-secondary --envs-per-gpu 131072 > "$out/pmc_131072.log" 2>&1 || echo "pmc 131072 failed"
 tail -12 "$out/pmc_d4.log"; tail -12 "$out/pmc_d7.log"; tail -24 "$out/pmc_131072.log"
+# gpurun merges at most 64 MiB back: keep the summaries, drop the raw rocprofv3 output
+for d in pmc_d4 pmc_d7 pmc_131072; do find "$out/$d" -mindepth 1 -maxdepth 1 -type d -exec rm -rf {} + ; done
+rm -rf "$out/trace"
+du -sh "$out"
