@@ -415,3 +415,22 @@ def test_gloo_stand_in_gathers_a_return_ring_row():
     ring, flat = _spawn(_ring_gather_worker, ())
     np.testing.assert_array_equal(ring, 200 + np.arange(11, dtype=np.float32))
     np.testing.assert_array_equal(flat, np.arange(11, dtype=np.float32))
+
+
+def test_bench_byte_models_and_traffic_lookup():
+    """The byte accounting bench.py's roofline uses: SURVEY 8(d)'s model, what one launch per step really moves, and what a
+    step moves when k steps share a launch (outputs every step, the state rows once per launch); the PMC traffic entry of a
+    configuration only answers for a run that launches the same way."""
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.algorithmic_bytes_per_env_step(4, 7) == 249 and bench.algorithmic_bytes_per_env_step(7, 7) == 285
+    assert bench.actual_bytes_per_env_step(4, 7) == 233 and bench.actual_bytes_per_env_step(7, 7) == 257
+    assert bench.moved_bytes_per_env_step(4, 7, 1) == 233 and bench.moved_bytes_per_env_step(7, 7, 1) == 257
+    assert bench.moved_bytes_per_env_step(4, 7, 5) == pytest.approx(101 + 132 / 5)
+    assert bench.moved_bytes_per_env_step(4, 7, 50) == pytest.approx(101 + 132 / 50)
+    one = bench.load_traffic("d4_k7_n1048576")
+    assert one is not None and 2.3e8 < one < 2.6e8
+    assert bench.load_traffic("d4_k7_n1048576", 5) is None                  # measured with one launch per step
+    five = bench.load_traffic("d4_k7_n131072", 5.0)
+    assert five is not None and 0.95 < five / (bench.moved_bytes_per_env_step(4, 7, 5) * 5 * 131072) < 1.1
+    assert bench.load_traffic("d4_k7_n131072") is None and bench.load_traffic("no_such_config") is None
