@@ -237,6 +237,7 @@ class EpisodeLoop:
         self.eng, self.seed, self.L, self.fused, self.overlap = engine, seed, int(episode_len), fused, overlap
         self.steps_per_launch = max(1, int(steps_per_launch))     # mt_rollout's k on small shards (engine.dispatch())
         self.kernel_launches = 0    # kernel launches (per env range) behind the timed steps: ceil(segment / k), 1 per fused segment
+        self.lap_steps = []         # steps inside every timed step lap, in lap order
         self.step = 0
         self.episode = 0
         self.gathers = 0
@@ -301,6 +302,7 @@ class EpisodeLoop:
             if time_kernels:
                 self.eng.lap_end("step")
                 launches += seg
+                self.lap_steps.append(seg)
                 self.kernel_launches += 1 if self.fused else -(-seg // self.steps_per_launch)
             self.step += seg
             done += seg
@@ -336,13 +338,25 @@ class TimedEngine:
         self._kinds = []
 
     def collect(self):
-        """Per-kind device milliseconds of the laps since start_region (synchronises once)."""
+        """Per-kind device milliseconds of the laps since start_region (synchronises once): the sums, and under
+        "step_laps" every step lap by itself.  A lap is [begin event .. latest end event]: an event recorded on an idle
+        stream completes at once, so a HOST stall between a lap's last launch and its end-event record (a first-use
+        allocation inside the HIP runtime: 80 ms observed, once per process, in whichever lap was the unlucky one) reads as
+        device time of that lap.  Callers therefore take the MEDIAN over laps / regions, never the plain sum."""
         ms = self.e.lap_times()
-        out = {"step": 0.0, "gather": 0.0}
+        out = {"step": 0.0, "gather": 0.0, "step_laps": []}
         for kind, v in zip(self._kinds, ms):
             out[kind] += v
+            if kind == "step":
+                out["step_laps"].append(v)
         self._kinds = []
         return out
+
+
+def robust_us_per_step(lap_ms, lap_steps):
+    """us per step from laps of known step counts: the median over laps of (lap time / its steps)."""
+    per = sorted(ms * 1e3 / max(1, st) for ms, st in zip(lap_ms, lap_steps))
+    return per[len(per) // 2] if per else 0.0
 
 
 def time_step_launches(m, n, table, radius, k, dev, seed, fused=False, steps=600, episode_len=50, want_spl=False, rollout_k=None):
@@ -368,8 +382,9 @@ def time_step_launches(m, n, table, radius, k, dev, seed, fused=False, steps=600
         loop.run(4 * episode_len)
         e.sync()
     e.start_region()
+    loop.lap_steps = []
     launches, _ = loop.run(steps, time_kernels=True)
-    us = e.collect()["step"] * 1e3 / launches
+    us = robust_us_per_step(e.collect()["step_laps"], loop.lap_steps)      # median over the episode laps
     name = "rollout_kernel (fused)" if fused else e.step_kernel_name()
     spl = launches / max(1, loop.kernel_launches)
     e.close()
@@ -402,20 +417,23 @@ def time_loaded_action_steps(m, n, table, radius, k, dev, seed, steps=600, episo
                 t += 1
             if timed:
                 e.lap_end()
+                seg_steps.append(seg)
             done += seg
+    seg_steps = []
     t0 = time.perf_counter()
     while time.perf_counter() - t0 < 0.15:
         pairs(200, False)
         e.sync()
     e.lap_times()
+    seg_steps = []
     pairs(steps, True)
-    us_pair = sum(e.lap_times()) * 1e3 / steps
+    us_pair = robust_us_per_step(e.lap_times(), seg_steps)                 # median over the chunk laps
     for rep in range(steps // chunk):
         e.lap_begin()
         for j in range(chunk):
             e.sample_actions(seed, rep * chunk + j)
         e.lap_end()
-    us_sample = sum(e.lap_times()) * 1e3 / (steps // chunk * chunk)
+    us_sample = robust_us_per_step(e.lap_times(), [chunk] * (steps // chunk))
     d = e.dispatch()["chains"]
     name = e.step_kernel_name().split(" [mt_rollout")[0].replace("step_kernel<", "step_kernel<SAMPLE=false, ") + \
         (f" [mt_step: {d['count']} chains of {d['span']} envs]" if d["count"] > 1 else "")
@@ -497,7 +515,7 @@ def measure(fab, raw, n_total, steps, warmup, episode_len, seed, fused=False, ov
     loop.run(warmup)                                            # the W untimed warm-up steps of the contract
     loop.align()                                                # the first timed region starts an episode
     fab.fence(raw)
-    regions, device_ms, kernel_ms, gather_ms, launches, gathers = [], [], 0.0, 0.0, 0, 0
+    regions, device_ms, step_us_regions, gather_ms, launches, gathers = [], [], [], 0.0, 0, 0
     for _ in range(reps):
         eng.start_region()
         fab.fence(raw)
@@ -509,7 +527,7 @@ def measure(fab, raw, n_total, steps, warmup, episode_len, seed, fused=False, ov
         regions.append(time.perf_counter() - t0)
         device_ms.append(raw.timer_read())
         ms = eng.collect()
-        kernel_ms += ms["step"]
+        step_us_regions.append(ms["step"] * 1e3 / max(1, ln))   # device time per step of THIS region (sum of its step laps)
         # overlapped: device time of the region's last exchange on the side stream; in line: HIP-event laps around it
         gather_ms += (raw.gather_wait(host=True) * gt if gt else 0.0) if loop.overlap else ms["gather"]
         launches += ln
@@ -524,8 +542,10 @@ def measure(fab, raw, n_total, steps, warmup, episode_len, seed, fused=False, ov
     assert np.all(g == np.round(g)) and np.abs(g).max() <= L    # returns of an L-step episode
     elapsed = float(np.median(regions))
     dev_s = float(np.median(device_ms)) * 1e-3
+    step_us = float(np.median(step_us_regions))                 # median over regions: one stalled lap does not move it
     return {"elapsed": elapsed, "ms_per_step": elapsed / steps * 1e3, "ms_per_step_min": float(regions.min()) / steps * 1e3,
-            "ms_per_step_max": float(regions.max()) / steps * 1e3, "step_us": kernel_ms * 1e3 / max(1, launches),
+            "ms_per_step_max": float(regions.max()) / steps * 1e3, "step_us": step_us,
+            "step_us_max_region": float(np.max(step_us_regions)),
             "launches": launches, "gather_us": gather_ms * 1e3 / max(1, gathers), "gathers_per_region": gathers // reps,
             "repeats": reps, "prewarm": prewarm, "episode_len": L, "value": n_total * steps / elapsed,
             "region_device_ms": dev_s * 1e3, "device_ms_per_step": dev_s * 1e3 / steps,
@@ -945,10 +965,9 @@ def main():
                     "(sample_actions_us, measured in the same per-chain form) is subtracted; *_pair = the (sample, step) pair "
                     "as timed, against the bytes of both launches (SURVEY's 249 + the 4 D-byte action write)"}
         # BASELINE.json's other single-GPU configurations and the pure-HBM point, same kernel path, short runs.  Every
-        # configuration is measured on two fresh engines, once in this order and once more in the reverse order at the end:
-        # how fast an arena streams depends on where its pages physically landed, which depends on the allocations the
-        # process made before (the same configuration read 38 or 102-192 us by its position in this
-        # list), so one window per configuration is not a measurement.  us_per_step = the faster pass, both are listed.
+        # configuration is measured on two fresh engines, once in this order and once more in the reverse order at the end
+        # (us_per_step = the faster pass, both are listed): the 4 M-arm arena reads 171 or 193 us by where its pages landed
+        # (DESIGN.md section 5), and a second look at every figure is cheap.
         others = (("configs[1]: 65536 arms, 4-DoF", 65536, m.REF_DH_TABLE, 51.3),
                   ("131072 arms, 4-DoF (1 M arms over 8 GPUs, per-GPU shard)", 131072, m.REF_DH_TABLE, 51.3),
                   ("524288 arms, 4-DoF (configs[3] over 8 GPUs, per-GPU shard)", 524288, m.REF_DH_TABLE, 51.3),

@@ -855,9 +855,8 @@ int mt_create(mt_handle* out, const mt_config* cfg) {
                o_trace = take((cfg->flags & MT_FLAG_TRACE) ? (size_t)cfg->substeps * 3 * ld * 4 : 0),
                o_zmin = take((cfg->flags & MT_FLAG_DEBUG_ZMIN) ? ld * 4 : 0), o_trig = take(kTrigEntries * sizeof(SinCos));
   h->arena_bytes = off;
-  // (One experiment with hipExtMallocWithFlags(hipDeviceMallocContiguous) instead -- a physically contiguous arena -- did not
-  // remove the placement-dependent slow arenas described in DESIGN.md section 5 and cost 5 % at 1 M arms: dropped the same
-  // day, profiles/r04_variants.md section 3.)
+  // (One experiment with hipExtMallocWithFlags(hipDeviceMallocContiguous) instead -- a physically contiguous arena -- cost 5 %
+  // at 1 M arms and was dropped the same day: profiles/r04_variants.md section 3.)
   if (hipMalloc(&h->arena, h->arena_bytes) != hipSuccess) {
     (void)hipGetLastError();
     return bail(MT_ERR_ALLOC, "hipMalloc of the state arena failed (" + std::to_string(h->arena_bytes) + " bytes)");
@@ -1853,13 +1852,23 @@ int mt_timer_read(mt_handle h, float* elapsed_ms) {
   return MT_OK;
 }
 
-// one event of the lap pool, recorded on `stream`; its index
-static int lap_event(mt_handle h, hipStream_t stream, uint32_t* index) {
-  if (h->lap_events_used == h->lap_events.size()) {
+// The lap pool holds at least `count` unused events.  Called at the BEGIN of a lap for the whole lap (its begin event and one
+// end event per stream), ahead of the begin event's record: creating an event can stall the host for milliseconds (80 ms
+// observed, once per process, inside the HIP runtime), and a host stall between a lap's last launch and the record of its
+// end event would read as device time of the lap -- an event recorded on an idle stream completes at once.
+static int lap_reserve(mt_handle h, size_t count) {
+  while (h->lap_events.size() < h->lap_events_used + count) {
     hipEvent_t e = nullptr;
     MT_HIP(h, hipEventCreateWithFlags(&e, event_flags(true)));
     h->lap_events.push_back(e);
   }
+  return MT_OK;
+}
+
+// one event of the lap pool, recorded on `stream`; its index
+static int lap_event(mt_handle h, hipStream_t stream, uint32_t* index) {
+  int rcr = lap_reserve(h, 1);
+  if (rcr) return rcr;
   MT_HIP(h, hipEventRecord(h->lap_events[h->lap_events_used], stream));
   *index = (uint32_t)h->lap_events_used++;
   return MT_OK;
@@ -1870,7 +1879,9 @@ int mt_timer_lap_begin(mt_handle h) {
   if (h->lap_open) return fail(h, MT_ERR_STATE, "mt_timer_lap_begin: a lap is already open");
   MT_ENTER(h);  // a lap starts on the handle's stream with everything before it folded in
   mt_engine::LapRec rec{0, 0, 0};
-  int rc = lap_event(h, h->stream, &rec.begin);
+  int rc = lap_reserve(h, 1 + (size_t)mt_engine::kMaxChains);  // the whole lap's events exist before it begins
+  if (rc) return rc;
+  rc = lap_event(h, h->stream, &rec.begin);
   if (rc) return rc;
   h->lap_recs.push_back(rec);
   h->lap_open = true;

@@ -40,7 +40,8 @@ def assert_same(got, want, what=""):
 @pytest.mark.parametrize("chains", ["1", "2", "3"])
 @pytest.mark.parametrize("rk", ["2", "4", "5", None])
 @pytest.mark.parametrize("n,k,table_name", [(131072, 7, "ref"), (65536, 7, "ref"), (100003, 3, "ref"), (777, 9, "ref"),
-                                            (70001, 7, "dh7"), (9001, 5, "rt5"), (262144, 7, "ref")])
+                                            (70001, 7, "dh7"), (9001, 5, "rt5"), (262144, 7, "ref"), (3001, 32, "ref"),
+                                            (200003, 1, "dh7"), (140000, 12, "ref")])
 def test_rollout_k_steps_per_launch_equals_launch_per_step(m, monkeypatch, n, k, table_name, rk, chains):
     """On small shards (kPolicy.multi_step_max envs; any size with MT_ROLLOUT_K) mt_rollout runs k steps per launch through the rollout kernels (kPolicy.multi_step_*,
     MT_ROLLOUT_K; per chain on multi-chain handles).  State after the call and the outputs of its last step must equal
@@ -76,6 +77,29 @@ def test_rollout_k_steps_per_launch_equals_launch_per_step(m, monkeypatch, n, k,
                 e.reset_done(6)                  # queued on the handle's stream: must see every chain's last launch
         step += T
         assert_same(snapshot(m, eng), snapshot(m, ref), f"T={T}")
+    ref.close()
+    eng.close()
+
+
+@pytest.mark.parametrize("kw", [dict(terminate_on_ground=True), dict(substeps=2), dict(substeps=24), dict(specialize=False),
+                                dict(pickup_tol=60.0)])
+def test_rollout_k_steps_per_launch_with_other_engine_options(m, monkeypatch, kw):
+    """The multi-step form under the options that change what a step computes: ground contact ends the episode, the
+    shortest and an even number of sub-steps, the runtime-table kernels of the reference arm, a pickup box that finishes
+    episodes quickly -- each against the launch-per-step engine, with a reset_done in between."""
+    n, k = 50000, 4
+    monkeypatch.setenv("MT_ROLLOUT_K", "1")
+    ref = m.StepEngine(n, k, **kw)
+    monkeypatch.delenv("MT_ROLLOUT_K")
+    eng = m.StepEngine(n, k, **kw)
+    assert eng.dispatch()["rollout"]["form"] == "multi_step" and ref.dispatch()["rollout"]["steps_per_launch"] == 1
+    for e in (ref, eng):
+        e.reset_random(3, 0)
+        e.rollout(11, 3, 0)
+        e.reset_done(3)
+        e.rollout(7, 3, 11)
+    assert_same(snapshot(m, eng), snapshot(m, ref), str(kw))
+    assert ref.done().any() or "substeps" in kw or "specialize" in kw
     ref.close()
     eng.close()
 
