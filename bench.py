@@ -354,9 +354,15 @@ class TimedEngine:
 
 
 def robust_us_per_step(lap_ms, lap_steps):
-    """us per step from laps of known step counts: the median over laps of (lap time / its steps)."""
-    per = sorted(ms * 1e3 / max(1, st) for ms, st in zip(lap_ms, lap_steps))
-    return per[len(per) // 2] if per else 0.0
+    """us per step from laps of known step counts: the step-weighted mean over the laps (so that the mix of early-episode
+    and late-episode steps stays what it is), without the laps whose per-step time exceeds three times the median lap's --
+    a host stall booked as device time (TimedEngine.collect) reads 10-100 x, nothing the device does reads 3 x."""
+    per = [ms * 1e3 / max(1, st) for ms, st in zip(lap_ms, lap_steps)]
+    if not per:
+        return 0.0
+    med = sorted(per)[len(per) // 2]
+    keep = [(ms, st) for ms, st, p_ in zip(lap_ms, lap_steps, per) if p_ <= 3.0 * med]
+    return sum(ms for ms, _ in keep) * 1e3 / max(1, sum(st for _, st in keep))
 
 
 def time_step_launches(m, n, table, radius, k, dev, seed, fused=False, steps=600, episode_len=50, want_spl=False, rollout_k=None):
@@ -384,7 +390,7 @@ def time_step_launches(m, n, table, radius, k, dev, seed, fused=False, steps=600
     e.start_region()
     loop.lap_steps = []
     launches, _ = loop.run(steps, time_kernels=True)
-    us = robust_us_per_step(e.collect()["step_laps"], loop.lap_steps)      # median over the episode laps
+    us = robust_us_per_step(e.collect()["step_laps"], loop.lap_steps)      # mean over the episode laps, stalled laps dropped
     name = "rollout_kernel (fused)" if fused else e.step_kernel_name()
     spl = launches / max(1, loop.kernel_launches)
     e.close()
@@ -427,7 +433,7 @@ def time_loaded_action_steps(m, n, table, radius, k, dev, seed, steps=600, episo
     e.lap_times()
     seg_steps = []
     pairs(steps, True)
-    us_pair = robust_us_per_step(e.lap_times(), seg_steps)                 # median over the chunk laps
+    us_pair = robust_us_per_step(e.lap_times(), seg_steps)                 # mean over the chunk laps, stalled laps dropped
     for rep in range(steps // chunk):
         e.lap_begin()
         for j in range(chunk):
