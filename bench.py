@@ -408,12 +408,17 @@ def time_loaded_action_steps(m, n, table, radius, k, dev, seed, steps=600, episo
     """us per mt_step when the actions come from HBM, as with a policy in the loop (step_kernel<SAMPLE = false>: exactly
     SURVEY 8(d)'s byte model incl. the 4D-byte action read).  The actions of every step are written by mt_sample_actions (a
     separate small launch), so the arms move as in the headline.  On a multi-chain handle both calls are issued per chain
-    (each half of the env range on its own stream, left forked from call to call).  HIP-event laps around chunks of `chunk`
-    (sample, step) pairs, minus laps around chunks of `chunk` sample launches alone in the same per-chain form: a lap
-    around every single launch would add the cost of its two event records to a 40 us kernel.
-    -> (us per step = pair - sample, us per sample launch, us per pair as timed, kernel name)."""
+    (each half of the env range on its own stream, left forked from call to call).  What is TIMED is the (sample, step)
+    pair: HIP-event laps around chunks of `chunk` pairs (a lap around every single launch would add the cost of its two
+    event records to a 40 us kernel).  The step's own time is the pair minus the sampler's cheapest form -- ONE launch over
+    the whole batch, timed alone on a caller's stream, where the per-step calls are single launches: a lower bound of what
+    the sampler costs inside the pair, hence an upper bound of the step (subtracting the per-chain sampler timed alone read
+    6.5-10 us at 1 M arms from run to run -- two tiny launches and their fork -- and flattered the step by as much).
+    -> (us per step = pair - single-launch sample, us per sample launch, us per pair as timed, kernel name)."""
+    import torch
     e = m.StepEngine(n, k, dh_table=table, radius=radius, device=dev)
     t = 0
+    seg_steps = []
 
     def pairs(count, timed):
         nonlocal t
@@ -432,24 +437,24 @@ def time_loaded_action_steps(m, n, table, radius, k, dev, seed, steps=600, episo
                 e.lap_end()
                 seg_steps.append(seg)
             done += seg
-    seg_steps = []
     t0 = time.perf_counter()
     while time.perf_counter() - t0 < 0.15:
         pairs(200, False)
         e.sync()
     e.lap_times()
-    seg_steps = []
     pairs(steps, True)
     us_pair = robust_us_per_step(e.lap_times(), seg_steps)                 # mean over the chunk laps, stalled laps dropped
+    d = e.dispatch()["chains"]
+    name = e.step_kernel_name().split(" [mt_rollout")[0].replace("step_kernel<", "step_kernel<SAMPLE=false, ") + \
+        (f" [mt_step: {d['count']} chains of {d['span']} envs]" if d["count"] > 1 else "")
+    torch.cuda.synchronize()
+    e.use_torch_stream()                                                   # per-step calls are single launches here
     for rep in range(steps // chunk):
         e.lap_begin()
         for j in range(chunk):
             e.sample_actions(seed, rep * chunk + j)
         e.lap_end()
     us_sample = robust_us_per_step(e.lap_times(), [chunk] * (steps // chunk))
-    d = e.dispatch()["chains"]
-    name = e.step_kernel_name().split(" [mt_rollout")[0].replace("step_kernel<", "step_kernel<SAMPLE=false, ") + \
-        (f" [mt_step: {d['count']} chains of {d['span']} envs]" if d["count"] > 1 else "")
     e.close()
     return us_pair - us_sample, us_sample, us_pair, name
 
@@ -974,9 +979,10 @@ def main():
             "frac_of_hbm_peak_pair": (bpe + 4 * args.dof) * n_local / (us_pair * 1e-6) / 1e9 / HBM_PEAK_GBS,
             "note": "mt_step with the actions read from HBM (policy-in-the-loop shape, step_kernel<SAMPLE = false>): "
                     "the kernel that moves exactly the SURVEY 8(d) bytes, issued per chain like mt_rollout's steps; the "
-                    "actions are written by a separate mt_sample_actions launch (per chain as well) whose own time "
-                    "(sample_actions_us, measured in the same per-chain form) is subtracted; *_pair = the (sample, step) pair "
-                    "as timed, against the bytes of both launches (SURVEY's 249 + the 4 D-byte action write)"}
+                    "actions are written by a separate mt_sample_actions launch (per chain as well).  TIMED is the (sample, "
+                    "step) pair (pair_us; frac_of_hbm_peak_pair = against the bytes of both launches, SURVEY's 249 + the 4 "
+                    "D-byte action write); us_per_step = pair_us minus the sampler's cheapest form (sample_actions_us: one "
+                    "launch over the batch, timed alone), i.e. an upper bound of the step's own time"}
         # BASELINE.json's other single-GPU configurations and the pure-HBM point, same kernel path, short runs.  Every
         # configuration is measured on two fresh engines, once in this order and once more in the reverse order at the end
         # (us_per_step = the faster pass, both are listed): the 4 M-arm arena reads 171 or 193 us by where its pages landed

@@ -191,7 +191,7 @@ MT_API int mt_sample_actions(mt_handle h, uint64_t seed, uint32_t step_idx);
 /* On a multi-chain handle (163 840 .. 3 M envs, see mt_rollout) that runs on its OWN stream the step is two launches, one
  * per half of the env range on its own stream; mt_set_actions from DEVICE memory and mt_sample_actions stage each half's
  * rows on the same streams, so a policy loop (set actions / step / ...) keeps the halves independent from call to call
- * (any other call and mt_sync fold them back): 42.3 -> 37.1 us per step at 1 M envs.  On a caller's stream (mt_set_stream)
+ * (any other call and mt_sync fold them back): 42 -> 37.5 us per step at 1 M envs.  On a caller's stream (mt_set_stream)
  * the step stays one launch: forking behind the caller's work and joining back for a single launch costs more than it
  * hides.  Same bits either way. */
 MT_API int mt_step(mt_handle h);
