@@ -971,6 +971,19 @@ def main():
             "env_steps_per_s": n_local / (us * 1e-6), "us_per_step": us, "steps_per_launch": 50,
             "note": "mt_rollout_fused: state stays in registers/LDS between steps, bit-identical results; "
                     "arithmetic-bound, so the per-step byte model does not apply"}}
+        if dispatch["rollout"]["steps_per_launch"] == 1 and dispatch["fused"]["usable"]:
+            # what the k-steps-per-launch form of small shards (kPolicy.multi_step_k) would give at THIS size: not the
+            # default here -- the headline stays the one-launch-per-step, HBM-bound path SURVEY 8(d)'s byte model describes
+            kk = int(dispatch["policy"]["multi_step_k"])
+            us_k, name_k, spl_k = time_step_launches(m, n_local, table, radius, args.targets, dev, args.seed, steps=600,
+                                                     want_spl=True, rollout_k=kk)
+            mv = moved_bytes_per_env_step(args.dof, args.targets, spl_k)
+            out["secondary"]["multi_step_rollout"] = {
+                "steps_per_launch": kk, "us_per_step": us_k, "env_steps_per_s": n_local / (us_k * 1e-6), "kernel": name_k,
+                "bytes_per_env_step": mv, "frac_of_hbm_peak": mv * n_local / (us_k * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                "note": f"MT_ROLLOUT_K={kk}: mt_rollout with {kk} steps per launch through the rollout kernels at the headline's "
+                        "size (the default only up to 262 144 envs): the state rows cross HBM once per launch, the step becomes "
+                        "arithmetic-bound; same bits"}
         us, us_sample, us_pair, lname = time_loaded_action_steps(m, n_local, table, radius, args.targets, dev, args.seed)
         out["secondary"]["loaded_action_step"] = {
             "us_per_step": us, "sample_actions_us": us_sample, "pair_us": us_pair, "kernel": lname,
