@@ -945,7 +945,8 @@ const char* mt_step_kernel_name(mt_handle h) {
                      ", pf=" + ((h->trig == 0 && !h->lds_table && h->prefetch) ? std::to_string(kPrefetch) : std::string("0")) +
                      ((h->trig == 0 && !h->lds_table && h->trig_steps) ? ", tt=1" : "") +
                      ((h->trig == 0 && !h->lds_table && h->prefetch && h->cfg.n_envs >= h->flat_from) ? ", flat=1>" : ">");
-  if (h->chains > 1)  // what mt_rollout launches instead: the schedule for a chain's env count, on row views
+  const bool multi_one_chain = h->multi_k > 1 && fusable(h) && !h->chains_forced;  // mt_rollout does not use the chains then
+  if (h->chains > 1 && !multi_one_chain)  // what mt_rollout launches instead: the schedule for a chain's env count, on row views
     h->kernel_name += " [mt_rollout: " + std::to_string(h->chains) + " chains of " + std::to_string(chain_span(h, h->chains)) +
                       " envs, " + (h->trig == 0 && !h->lds_table && h->chain_split ? "L=" + std::to_string(h->chain_split)
                                    : std::string(h->trig == 0 && !h->lds_table && h->chain_prefetch
