@@ -2,7 +2,9 @@
 """Randomised campaign over the SAMPLED-action paths (mt_reset_random / mt_rollout / mt_rollout_fused / mt_reset_done): random
 arm (reference, 7-joint, random table; sometimes with other observation / pickup rows), joint count, targets, sub-steps (incl. > 26: per-pose sincos dispatch), batch size
 (up to the sizes where mt_rollout runs as chains), and a random schedule forced through the environment -- MT_CHAINS 1..4,
-MT_GRAPH 0 / 1, MT_TRIG_TABLE 0 / 1, MT_SPLIT 0 / 2 / 4, MT_PREFETCH 0 / 1, MT_RESET_SPLIT 0 / 1.  Every case is checked two ways:
+MT_GRAPH 0 / 1, MT_TRIG_TABLE 0 / 1, MT_SPLIT 0 / 2 / 4, MT_PREFETCH 0 / 1, MT_RESET_SPLIT 0 / 1, and (round 4) MT_ROLLOUT_K 1 .. 9 with
+either prologue of the rollout kernels (MT_ROLLOUT_EARLY), plus staged-action steps (mt_sample_actions + mt_step: per chain on
+multi-chain handles) mixed into the plan.  Every case is checked two ways:
   * bit for bit against the plainest schedule of the same library (one chain, no graph, no table, one env per lane), all
     state and step-output fields, after a mix of rollouts, fused rollouts and reset_done calls;
   * against the CPU oracle (C restatement, stepped with the same Philox streams): the z-minimum of the last step
@@ -25,7 +27,8 @@ from oracle import philox_ref as px  # noqa: E402
 
 FIELDS = ("F_GOALS", "F_ALIVE", "F_TOTAL_REWARD", "F_POINTS", "F_EPISODES", "F_LAST_RETURN", "F_OBS", "F_REWARD", "F_DONE",
           "F_EE", "F_DONE_BITS", "F_ZMIN", "F_RETURN_RING")
-KNOBS = ("MT_CHAINS", "MT_GRAPH", "MT_TRIG_TABLE", "MT_SPLIT", "MT_PREFETCH", "MT_RESET_SPLIT", "MT_LAZY_CHAINS")
+KNOBS = ("MT_CHAINS", "MT_GRAPH", "MT_TRIG_TABLE", "MT_SPLIT", "MT_PREFETCH", "MT_RESET_SPLIT", "MT_LAZY_CHAINS", "MT_ROLLOUT_K",
+         "MT_ROLLOUT_EARLY")
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--minutes", type=float, default=3.0)
@@ -58,11 +61,12 @@ while time.time() < deadline:
     tol = float(rng.choice([3.0, 8.0, 25.0]))
     frames = dict(obs_frame=int(rng.randint(-dof, dof)), ee_frame=int(rng.randint(1, dof))) if rng.rand() < 0.15 else {}
     seed = int(rng.randint(1, 1 << 30))
-    plan = [(str(rng.choice(["rollout", "rollout", "fused", "fused_auto", "rollout_reset", "rollout_gather_reset"])), int(rng.randint(1, 12)))
+    plan = [(str(rng.choice(["rollout", "rollout", "fused", "fused_auto", "rollout_reset", "rollout_gather_reset", "staged"])), int(rng.randint(1, 12)))
             for _ in range(int(rng.randint(2, 6)))]
     knobs = {"MT_CHAINS": rng.randint(1, 5), "MT_GRAPH": rng.randint(2), "MT_TRIG_TABLE": rng.randint(2),
              "MT_SPLIT": rng.choice([0, 2, 4]), "MT_PREFETCH": rng.randint(2), "MT_RESET_SPLIT": rng.randint(2),
-             "MT_LAZY_CHAINS": int(rng.rand() < 0.8)}
+             "MT_LAZY_CHAINS": int(rng.rand() < 0.8), "MT_ROLLOUT_K": int(rng.choice([1, 1, 2, 3, 4, 5, 5, 9])),
+             "MT_ROLLOUT_EARLY": rng.randint(2)}
 
     def run(env):
         for key in KNOBS:
@@ -83,6 +87,10 @@ while time.time() < deadline:
                     e.rollout(steps, seed, t)
                     episode += 1
                     e.reset_random(seed, episode)
+                elif what == "staged":               # the policy path: actions staged on the device, then mt_step (per chain on
+                    for q in range(steps):           # multi-chain handles; the same Philox actions as the sampled path)
+                        e.sample_actions(seed, t + q)
+                        e.step()
                 elif what == "rollout_gather_reset":  # the benchmark's episode end: snapshot gather (per chain), then the reset
                     e.rollout(steps, seed, t)
                     gathered.append(e.gather_begin())
@@ -101,7 +109,7 @@ while time.time() < deadline:
         return out, p0, t + 2
 
     plain, p0, total = run({"MT_CHAINS": 1, "MT_GRAPH": 0, "MT_TRIG_TABLE": 0, "MT_SPLIT": 0, "MT_PREFETCH": 0, "MT_RESET_SPLIT": 0,
-                            "MT_LAZY_CHAINS": 0})
+                            "MT_LAZY_CHAINS": 0, "MT_ROLLOUT_K": 1, "MT_ROLLOUT_EARLY": 0})
     got, p1, _ = run(knobs)
     for f in plain:
         assert np.array_equal(plain[f], got[f]), (f, knobs, n, k, dof, substeps, plan, seed)
