@@ -468,16 +468,17 @@ class Fabric:
         self.host_barrier, self.device_sync = host_barrier, device_sync or (lambda: None)
 
     def fence(self, raw):
+        """torch.cuda.synchronize() + barrier.  The device is drained FIRST -- every stream of this rank, incl. an exchange
+        still running on the engine's side stream -- so that the barrier is passed only when every rank's device work is
+        complete (and a collective barrier never shares the device with an exchange of the other communicator); behind the
+        barrier nothing is outstanding anywhere, so no second synchronisation follows (it cost 13 us per fence doing
+        nothing: profiles/r03_region_host_latency.txt -- a tenth of a 20-step region of a 131 072-arm shard)."""
+        self.device_sync()
         if self.world > 1:
-            # drain this rank's own queues first (incl. an exchange still running on the engine's side stream): the
-            # barrier is then passed only when every rank's device work is complete, and a collective barrier never
-            # shares the device with an exchange of the other communicator
-            raw.sync()
             if self.host_barrier is not None:
                 self.host_barrier.wait()
             else:
                 self.dist.barrier()
-        self.device_sync()
 
     def rank0_says(self, flag):
         """Time-based loops contain collectives (the gathers): every rank must run the same number of them, so rank 0's
@@ -917,8 +918,8 @@ def main():
                        "gathers_in_timed_region": r["gathers_per_region"], "gather_mode": gather_mode(gather_fallback),
                        "launcher": os.environ.get("TORCHELASTIC_RUN_ID") and "torch.distributed.run" or
                                    ("bench.py self_launch (one fresh child process per rank)" if world > 1 else "none (one process)"),
-                       "timing": "median over `repeats` regions of exactly `steps` steps, each bracketed by barrier + "
-                                 "torch.cuda.synchronize(), max over ranks; value_device_timeline = the same regions on the "
+                       "timing": "median over `repeats` regions of exactly `steps` steps, each bracketed by "
+                                 "torch.cuda.synchronize() + barrier (device drained, then every rank arrived), max over ranks; value_device_timeline = the same regions on the "
                                  "device's clock (HIP events from the idle device at the region's start to the end of its "
                                  "last kernel / reset / exchange, max over ranks, median)",
                        "barrier": "none (one rank)" if world == 1 else
