@@ -824,12 +824,12 @@ def main():
 
     def regime_of(n_local, bytes_per_env):
         mb = bytes_per_env * n_local / 1e6
-        if mb < 150:
-            return ("on-die: the %.0f MB a step touches fit the L2s + the 256 MiB Infinity Cache, the step is bound by the "
-                    "kernel boundary and the dependent arithmetic of a few waves per SIMD, not by HBM" % mb)
+        if mb < 40:
+            return ("on-die: the %.0f MB a step touches fit the L2s (8 x 4 MB) and the 256 MiB Infinity Cache, the step is bound "
+                    "by the kernel boundary and the dependent arithmetic of a few waves per SIMD, not by HBM" % mb)
         if mb < 400:
-            return ("HBM + Infinity Cache: the %.0f MB a step touches are about the size of the 256 MiB MALL, so part of the "
-                    "re-read state is served on-die; the pure-HBM point is the 4 194 304-arm row" % mb)
+            return ("HBM + Infinity Cache: the %.0f MB a step touches are within (or about) the size of the 256 MiB MALL, so part "
+                    "of the re-read state is served on-die; the pure-HBM point is the 4 194 304-arm row" % mb)
         return "HBM (working set of %.0f MB per step, beyond the Infinity Cache)" % mb
 
     def leg_record(r, f, n_total, n_local, strong, label, name, fallback):
