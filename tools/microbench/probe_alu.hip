@@ -46,6 +46,87 @@ __global__ __launch_bounds__(BLOCK) void k_probe(float* state, float* out, unsig
   __builtin_nontemporal_store((unsigned char)(acc > 1.f ? 1 : 0), bytes + i);
 }
 
+// The same work with TWO envs per thread, software-pipelined: the loads of env B are in flight under the arithmetic of env A,
+// the stores of env A drain under the arithmetic of env B (each env gets its own ALU instructions).
+template <int ALU>
+__global__ __launch_bounds__(BLOCK) void k_probe2(float* state, float* out, unsigned char* bytes, long n, long ld) {
+  const long half = n / 2;
+  const long i = (long)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= half) return;
+  const long j = i + half;
+  float va[RD], vb[RD], acca = 0.f, accb = 0.f;
+#pragma unroll
+  for (int r = 0; r < RD; ++r) va[r] = state[(long)r * ld + i];
+#pragma unroll
+  for (int r = 0; r < RD; ++r) vb[r] = state[(long)r * ld + j];
+#pragma unroll
+  for (int r = 0; r < RD; ++r) acca += va[r];
+  const float m = 1.0000001f, a = 1e-9f;
+  {
+    float c0 = va[0], c1 = va[1], c2 = va[2], c3 = va[3], c4 = va[4], c5 = va[5], c6 = va[6], c7 = va[7];
+    for (int it = 0; it < ALU / 8; ++it) {
+      c0 = __builtin_fmaf(c0, m, a);
+      c1 = __builtin_fmaf(c1, m, a);
+      c2 = __builtin_fmaf(c2, m, a);
+      c3 = __builtin_fmaf(c3, m, a);
+      c4 = __builtin_fmaf(c4, m, a);
+      c5 = __builtin_fmaf(c5, m, a);
+      c6 = __builtin_fmaf(c6, m, a);
+      c7 = __builtin_fmaf(c7, m, a);
+    }
+    acca = (acca + c0 + c1 + c2 + c3 + c4 + c5 + c6 + c7) * 1e-30f;
+  }
+#pragma unroll
+  for (int r = 0; r < WN; ++r) __builtin_nontemporal_store(va[r % RD] + acca, out + (long)r * ld + i);
+#pragma unroll
+  for (int r = 0; r < WP; ++r) {
+    const int row = r < D ? r : RD - 2 + (r - D);
+    state[(long)row * ld + i] = va[row] + acca;
+  }
+  __builtin_nontemporal_store((unsigned char)(acca > 1.f ? 1 : 0), bytes + i);
+#pragma unroll
+  for (int r = 0; r < RD; ++r) accb += vb[r];
+  {
+    float c0 = vb[0], c1 = vb[1], c2 = vb[2], c3 = vb[3], c4 = vb[4], c5 = vb[5], c6 = vb[6], c7 = vb[7];
+    for (int it = 0; it < ALU / 8; ++it) {
+      c0 = __builtin_fmaf(c0, m, a);
+      c1 = __builtin_fmaf(c1, m, a);
+      c2 = __builtin_fmaf(c2, m, a);
+      c3 = __builtin_fmaf(c3, m, a);
+      c4 = __builtin_fmaf(c4, m, a);
+      c5 = __builtin_fmaf(c5, m, a);
+      c6 = __builtin_fmaf(c6, m, a);
+      c7 = __builtin_fmaf(c7, m, a);
+    }
+    accb = (accb + c0 + c1 + c2 + c3 + c4 + c5 + c6 + c7) * 1e-30f;
+  }
+#pragma unroll
+  for (int r = 0; r < WN; ++r) __builtin_nontemporal_store(vb[r % RD] + accb, out + (long)r * ld + j);
+#pragma unroll
+  for (int r = 0; r < WP; ++r) {
+    const int row = r < D ? r : RD - 2 + (r - D);
+    state[(long)row * ld + j] = vb[row] + accb;
+  }
+  __builtin_nontemporal_store((unsigned char)(accb > 1.f ? 1 : 0), bytes + j);
+}
+
+template <int ALU>
+static float run2(float* state, float* out, unsigned char* bytes, long n, long ld, hipStream_t st, int reps) {
+  auto pass = [&]() { hipLaunchKernelGGL((k_probe2<ALU>), dim3((unsigned)(n / 2 / BLOCK)), dim3(BLOCK), 0, st, state, out, bytes, n, ld); };
+  for (int w = 0; w < 5; ++w) pass();
+  (void)hipDeviceSynchronize();
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
+  (void)hipEventRecord(e0, st);
+  for (int r = 0; r < reps; ++r) pass();
+  (void)hipEventRecord(e1, st);
+  (void)hipEventSynchronize(e1);
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  return ms * 1e3f / reps;
+}
+
 template <int ALU>
 static float run(float* state, float* out, unsigned char* bytes, long n, long ld, int chains, hipStream_t* st, int reps) {
   const long per = n / chains;
@@ -90,6 +171,14 @@ int main(int argc, char** argv) {
                 t2048 = run<2048>(state, out, bytes, n, ld, chains, st, 200);
     printf("%d launch(es) per pass: ALU 0: %6.2f (%5.0f)  256: %6.2f  512: %6.2f  768: %6.2f  1024: %6.2f  1536: %6.2f  2048: %6.2f\n", chains, t0,
            gb / (t0 * 1e-6), t256, t512, t768, t1024, t1536, t2048);
+  }
+  {
+    const float t0 = run2<0>(state, out, bytes, n, ld, st[0], 200), t256 = run2<256>(state, out, bytes, n, ld, st[0], 200),
+                t512 = run2<512>(state, out, bytes, n, ld, st[0], 200), t768 = run2<768>(state, out, bytes, n, ld, st[0], 200),
+                t1024 = run2<1024>(state, out, bytes, n, ld, st[0], 200), t1536 = run2<1536>(state, out, bytes, n, ld, st[0], 200),
+                t2048 = run2<2048>(state, out, bytes, n, ld, st[0], 200);
+    printf("two envs per thread, pipelined (ALU per env): ALU 0: %6.2f (%5.0f)  256: %6.2f  512: %6.2f  768: %6.2f  1024: %6.2f  1536: %6.2f  2048: %6.2f\n",
+           t0, gb / (t0 * 1e-6), t256, t512, t768, t1024, t1536, t2048);
   }
   return 0;
 }
