@@ -939,7 +939,8 @@ def main():
                                   "where mt_rollout runs several steps per launch (counterpart: bytes_per_launch)",
                 "kernel": (f"rollout_kernel<{table_name}> ({L} steps per launch; us per step quoted)" if args.fused else
                            kernel_name + " (action drawn in-kernel)"),
-                "bytes_per_env_step": moved, "avg_kernel_us": r["step_us"], "steps_timed": r["launches"],
+                "bytes_per_env_step": moved, "avg_kernel_us": r["step_us"], "avg_kernel_us_max_region": r["step_us_max_region"],
+                "steps_timed": r["launches"],
                 "steps_per_kernel_launch": spl,
                 "launches_per_step": chains, "envs_per_launch": envs_per_launch,
                 "bytes_per_launch": moved * spl * envs_per_launch, "bytes_per_step": moved * n_local,
