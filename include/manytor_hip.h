@@ -213,17 +213,18 @@ MT_API int mt_bad_action_count(mt_handle h, uint64_t* count);
 MT_API int mt_step_random(mt_handle h, uint64_t seed, uint32_t step_idx);
 /* n_steps x mt_step_random with step indices step_idx0, step_idx0+1, ... (the
  * inner loop of test_multi.py:19-21).  The call exposes the state after n_steps steps and the outputs of the LAST one
- * (obs, reward, done, end effector), so on small shards (<= 131 072 envs) it runs FIVE steps per launch through the
+ * (obs, reward, done, end effector), so on small shards (<= 262 144 envs) it runs FIVE steps per launch through the
  * kernels of mt_rollout_fused -- joint angles, alive mask and return in registers, targets in LDS between them; every
  * step still computes and writes its outputs -- bit-identical to the launch-per-step sequence, without four of five
  * kernel boundaries and state re-fetches (MT_ROLLOUT_K=1 gives one launch per step back; then batches <= 131 072 envs are
  * replayed from a HIP graph that the handle captures once per segment length).
- * On large batches (163 840 .. 3 M envs) the call runs as TWO independent chains of launches -- the two halves of the env
+ * On large batches (above 262 144 and up to 3 M envs; from 163 840 with MT_ROLLOUT_K=1) the call runs as TWO independent chains of launches -- the two halves of the env
  * range (256-aligned) on two streams forked from the handle's stream: a step of env i depends only on env i, so the
  * results are bit-identical, and one half's kernel boundary is hidden behind the other half's kernel (-10 % per step at
  * 1 M envs).  On the handle's own stream the chains stay forked when the call returns: the next mt_rollout continues them,
  * mt_reset_random resets each half behind its own last step, mt_gather_returns_begin snapshots each half on its chain;
- * every other call -- mt_sync, getters, setters, mt_step, mt_reset_done, timers' begin ... -- folds them back into the
+ * mt_step / mt_sample_actions / mt_set_actions(device) run per half as well (see mt_step); every other call -- mt_sync,
+ * getters, setters, mt_reset_done, timers' begin ... -- folds them back into the
  * handle's stream first, so "mt_sync before foreign reads" means what it did.  On a caller's stream (mt_set_stream) the
  * chains are joined before the call returns: work queued on that stream afterwards sees the completed rollout. */
 MT_API int mt_rollout(mt_handle h, int n_steps, uint64_t seed, uint32_t step_idx0);
