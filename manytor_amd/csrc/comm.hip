@@ -437,6 +437,11 @@ static int gather_begin_impl(mt_handle h, int field, int row, float* dst, int64_
   // reset queued next then runs beside the exchange instead of behind a join.  Everything else joins first.
   const bool per_chain = !inplace && h->forked && h->lazy_chains && h->stream == h->own_stream;
   MT_ON_DEVICE(h, h->cfg.device);
+  rc = mt::flush_pending_reset(h);  // (a reset deferred into the next mt_rollout changes the rows this call reads)
+  if (rc) return rc;
+  // mt_rollout's last launch already stored the returns to the snapshot row and nothing has touched them since: no copy
+  const bool have_snap = !inplace && h->snap_valid && src == h->args.total_reward && h->snap != nullptr;
+  h->snap_valid = false;
   if (!per_chain) {
     rc = mt::join_chains(h);
     if (rc) return rc;
@@ -468,8 +473,10 @@ static int gather_begin_impl(mt_handle h, int field, int row, float* dst, int64_
         if (rc) return rc;
       }
       const int64_t cnt = std::min(span, h->n - off);
-      rc = row_copy(h, h->snap + off, src + off, cnt, sc);
-      if (rc) return rc;
+      if (!have_snap) {
+        rc = row_copy(h, h->snap + off, src + off, cnt, sc);
+        if (rc) return rc;
+      }
       if (c > 0) {
         if (!h->ev_join[c]) return fail(h, MT_ERR_STATE, "mt_gather_returns_begin: chain without its event");
         // (ev_join[c] is free while the chains are forked: a join records it afresh)
@@ -479,8 +486,10 @@ static int gather_begin_impl(mt_handle h, int field, int row, float* dst, int64_
     }
     src = h->snap;
   } else if (!inplace) {
-    rc = row_copy(h, h->snap, src, h->n, h->stream);
-    if (rc) return rc;
+    if (!have_snap) {
+      rc = row_copy(h, h->snap, src, h->n, h->stream);
+      if (rc) return rc;
+    }
     src = h->snap;
   }
   MT_HIP(h, hipEventRecord(h->ev_snap, h->stream));

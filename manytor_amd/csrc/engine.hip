@@ -294,6 +294,18 @@ static void choose_dispatch(mt_handle h) {
     h->multi_k = (int)std::max<long long>(1, std::min<long long>(64, v));
     seen("MT_ROLLOUT_K");
   }
+  // ... which absorb the episode boundary: a deferred full reset as the first launch's prologue, the gather's snapshot as
+  // the last launch's epilogue (kernels.h RolloutArgs)
+  h->defer_reset = true;
+  if (env_int("MT_DEFER_RESET", &v)) {
+    h->defer_reset = v != 0;
+    seen("MT_DEFER_RESET");
+  }
+  h->snap_in_rollout = true;
+  if (env_int("MT_ROLLOUT_SNAP", &v)) {
+    h->snap_in_rollout = v != 0;
+    seen("MT_ROLLOUT_SNAP");
+  }
   // ... whose launches take the prologue that runs the first step under the state loads (kernels.h RPF; static tables)
   h->rollout_early = true;
   if (env_int("MT_ROLLOUT_EARLY", &v)) {
@@ -990,7 +1002,8 @@ const char* mt_describe_dispatch(mt_handle h) {
       ",\"rollout\":{\"form\":\"" + (multi ? "multi_step" : (h->chains > 1 ? "chained_steps" : (graph ? "graph_replay" : "launch_per_step"))) +
       "\",\"steps_per_launch\":" + num(multi ? h->multi_k : 1) + ",\"graph\":" + b(!multi && graph) +
       ",\"lanes_per_env\":" + num(std::max(1, multi ? ((h->chains > 1 && h->chains_forced) ? h->chain_rollout_split : h->rollout_split) : (rec ? (h->chains > 1 ? h->chain_split : h->split) : 0))) +
-      ",\"chains\":" + num(multi && !h->chains_forced ? 1 : h->chains) + "}" +
+      ",\"chains\":" + num(multi && !h->chains_forced ? 1 : h->chains) +
+      ",\"absorbs_reset\":" + b(multi && h->defer_reset) + ",\"writes_snapshot\":" + b(multi && h->snap_in_rollout) + "}" +
       ",\"fused\":{\"usable\":" + b(fusable(h)) + ",\"lanes_per_env\":" + num(h->rollout_split ? h->rollout_split : 1) + "}" +
       ",\"reset\":{\"lanes_per_env\":" + num(h->reset_split ? 4 : 1) + "}" +
       ",\"overrides\":\"" + h->overrides + "\"" +
@@ -1087,9 +1100,8 @@ int mt_reset(mt_handle h, const float* points, int layout, int is_device) {
   return MT_OK;
 }
 
-static int reset_random_impl(mt_handle h, uint64_t seed, uint32_t episode, int mode) {
-  MT_REQUIRE(nullptr, h != nullptr, "handle is NULL");
-  MT_ON_DEVICE(h, h->cfg.device);
+// mode 1: full random reset; 2: re-arm finished envs only.  The launches themselves (no deferral).
+static int launch_reset_random(mt_handle h, uint64_t seed, uint32_t episode, int mode) {
   // A full random reset of a multi-chain handle is issued per chain, behind that chain's own last step, and leaves the
   // chains forked: one range's reset runs beside the other range's last step instead of behind a join.
   // (only WHILE they are forked: behind a joined call -- the multi-step mt_rollout of small shards, a getter -- the reset
@@ -1132,6 +1144,46 @@ static int reset_random_impl(mt_handle h, uint64_t seed, uint32_t episode, int m
   if (rc) return rc;
   h->is_reset = true;
   return MT_OK;
+}
+
+}  // extern "C" (interrupted: the next function has C++ linkage, engine_internal.h)
+
+namespace mt {
+int flush_pending_reset(mt_handle h) {
+  if (!h->reset_pending) return MT_OK;
+  h->reset_pending = false;
+  return launch_reset_random(h, h->pend_seed, h->pend_episode, 1);
+}
+}  // namespace mt
+
+extern "C" {
+
+// Does mt_rollout(n_steps >= 2) on this handle run k steps per launch through the rollout kernels right now?
+static bool rollout_is_multi_step(mt_handle h) { return h->multi_k > 1 && fusable(h); }
+
+static int reset_random_impl(mt_handle h, uint64_t seed, uint32_t episode, int mode) {
+  MT_REQUIRE(nullptr, h != nullptr, "handle is NULL");
+  MT_ON_DEVICE(h, h->cfg.device);
+  h->snap_valid = false;
+  int rc = flush_pending_reset(h);  // an earlier deferred reset comes first (its last_return is what this one overwrites)
+  if (rc) return rc;
+  // A full reset of a handle whose mt_rollout runs k steps per launch is DEFERRED into the first launch of the next
+  // mt_rollout (RolloutArgs::reset_first: the same state, bit for bit, without the reset's launch and without re-fetching what
+  // it would have written: an episode end of a 131 072-env shard goes from 20 to 6 us on the device, tools/episode_end_cost.py).
+  // Any other entry point launches it first (MT_ENTER).  Not while the chains are forked (the per-chain reset above).
+  if (mode == 1 && h->defer_reset && rollout_is_multi_step(h) && !h->forked) {
+    h->args.seed_lo = (uint32_t)seed;
+    h->args.seed_hi = (uint32_t)(seed >> 32);
+    h->args.major = episode;
+    h->args.episode0 = episode;
+    if (!h->goals_exposed) h->args.flags |= kFlagWholeGoals;
+    h->reset_pending = true;
+    h->pend_seed = seed;
+    h->pend_episode = episode;
+    h->is_reset = true;
+    return MT_OK;
+  }
+  return launch_reset_random(h, seed, episode, mode);
 }
 
 int mt_reset_random(mt_handle h, uint64_t seed, uint32_t episode) { return reset_random_impl(h, seed, episode, 1); }
@@ -1249,6 +1301,11 @@ int mt_step(mt_handle h) {
   const int chains = usable_chains(h, true);
   if (chains > 1) {
     MT_ON_DEVICE(h, h->cfg.device);
+    h->snap_valid = false;
+    {
+      int rcf = flush_pending_reset(h);
+      if (rcf) return rcf;
+    }
     const StepArgs a = h->args;
     int rc = per_chain(h, chains, "step_kernel (per chain)", [&](int c, int64_t, int64_t) { launch_chain(h, a, a.major, 1, chains, c, false); });
     h->args.flags &= ~kFlagWholeGoals;  // staged actions are anybody's floats
@@ -1489,26 +1546,61 @@ int mt_rollout(mt_handle h, int n_steps, uint64_t seed, uint32_t step_idx0) {
   // several independent chains of launches (env ranges on separate streams) where that pays; a caller who is capturing
   // the handle's stream gets the plain single-stream sequence
   int chains = n_steps >= 2 ? usable_chains(h) : 1;
+  h->snap_valid = false;  // the returns are about to change
+  const bool multi = n_steps >= 2 && rollout_is_multi_step(h);
+  if (h->reset_pending && !multi) {  // a deferred reset and a form that cannot absorb it: launch it now
+    int rc = flush_pending_reset(h);
+    if (rc) return rc;
+  }
   // Small shards: k steps per launch through the rollout kernels (kPolicy.multi_step_*).  The call exposes the state after
   // n_steps steps and the outputs of the last one either way; every step still writes its outputs.  One chain (see
-  // kPolicy) unless MT_CHAINS asks for more.
-  if (h->multi_k > 1 && n_steps >= 2 && fusable(h)) {
+  // kPolicy) unless MT_CHAINS asks for more.  The episode boundary rides along: a deferred full reset becomes the prologue
+  // of the first launch, and the last launch also stores the returns to the overlapped gather's snapshot row.
+  if (multi) {
     if (!h->chains_forced) chains = 1;
     StepArgs a = h->args;
     a.seed_lo = (uint32_t)seed;
     a.seed_hi = (uint32_t)(seed >> 32);
+    const bool fresh = h->reset_pending;
+    h->reset_pending = false;
+    // the snapshot row may be written only while no exchange is still reading it (the previous one has finished long ago
+    // in an episode loop: asked, not waited for) and only on the handle's stream proper
+    bool snap = h->snap_in_rollout && h->snap != nullptr;
+    if (snap && h->gather_pending) {
+      if (hipEventQuery(h->ev_g1) != hipSuccess) {
+        (void)hipGetLastError();
+        snap = false;
+      }
+    }
+    auto args_of = [&](int s0) {
+      RolloutArgs r{std::min(h->multi_k, n_steps - s0), step_idx0 + (uint32_t)s0, 0u, h->cfg.radius, 0u, 0u, 0u, 0u, nullptr};
+      if (fresh && s0 == 0) {
+        r.reset_first = 1u;
+        r.reset_episode = h->pend_episode;
+        r.reset_seed_lo = (uint32_t)h->pend_seed;
+        r.reset_seed_hi = (uint32_t)(h->pend_seed >> 32);
+      }
+      if (snap && s0 + h->multi_k >= n_steps) r.snap = h->snap;
+      return r;
+    };
     int rc = MT_OK;
+    if (fresh) {  // the in-kernel reset writes MT_F_LAST_RETURN: behind an exchange that still reads that row in place
+      rc = order_behind_inplace_gather(h, h->stream);
+      if (rc) return rc;
+    }
     if (chains > 1) {
       rc = fork_chains(h, chains);
       if (rc) return rc;
       const int64_t span = chain_span(h, chains);
       hipStream_t root = h->stream;
       for (int s0 = 0; s0 < n_steps; s0 += h->multi_k) {
-        const RolloutArgs r{std::min(h->multi_k, n_steps - s0), step_idx0 + (uint32_t)s0, 0u, h->cfg.radius};
         for (int c = 0; c < chains; ++c) {
           const int64_t off = (int64_t)c * span;
           if (off >= h->n) continue;
           h->stream = c == 0 ? root : h->chain_streams[c];
+          RolloutArgs r = args_of(s0);
+          if (r.snap) r.snap += off;
+          if (fresh && s0 == 0 && c > 0) (void)order_behind_inplace_gather(h, h->stream);
           launch_rollout(h, args_for_range(h, a, off, std::min(span, h->n - off)), h->chain_rollout_split, r, h->rollout_early);
         }
       }
@@ -1519,13 +1611,11 @@ int mt_rollout(mt_handle h, int n_steps, uint64_t seed, uint32_t step_idx0) {
     } else {
       rc = join_chains(h);
       if (rc) return rc;
-      for (int s0 = 0; s0 < n_steps; s0 += h->multi_k) {
-        const RolloutArgs r{std::min(h->multi_k, n_steps - s0), step_idx0 + (uint32_t)s0, 0u, h->cfg.radius};
-        launch_rollout(h, a, h->rollout_split, r, h->rollout_early);
-      }
+      for (int s0 = 0; s0 < n_steps; s0 += h->multi_k) launch_rollout(h, a, h->rollout_split, args_of(s0), h->rollout_early);
       rc = check_launch(h, "rollout_kernel (mt_rollout)");
     }
     if (rc) return rc;
+    h->snap_valid = snap;
     h->args.seed_lo = (uint32_t)seed;
     h->args.seed_hi = (uint32_t)(seed >> 32);
     h->args.major = step_idx0 + (uint32_t)(n_steps - 1);
@@ -1623,7 +1713,7 @@ int mt_rollout_fused(mt_handle h, int n_steps, uint64_t seed, uint32_t step_idx0
     int rcg = order_behind_inplace_gather(h, h->stream);
     if (rcg) return rcg;
   }
-  RolloutArgs r{n_steps, step_idx0, auto_reset ? 1u : 0u, h->cfg.radius};
+  RolloutArgs r{n_steps, step_idx0, auto_reset ? 1u : 0u, h->cfg.radius, 0u, 0u, 0u, 0u, nullptr};
   launch_rollout(h, h->args, h->rollout_split, r);
   return check_launch(h, "rollout_kernel");
 }
@@ -1780,6 +1870,12 @@ int mt_device_ptr(mt_handle h, int field, void** ptr, int64_t* rows, int64_t* ld
   FieldInfo fi{};
   int rc = field_info(h, field, &fi);
   if (rc) return rc;
+  if (h->reset_pending) {  // the caller is about to look at (or write) the rows themselves
+    MT_ON_DEVICE(h, h->cfg.device);
+    rc = flush_pending_reset(h);
+    if (rc) return rc;
+  }
+  h->snap_valid = false;
   if (field == MT_F_GOALS) {
     // the caller can now write joint angles behind the library's back at any time: the host's knowledge that every
     // angle is a whole degree (kFlagWholeGoals: table look-ups for the pose a step starts from) ends here, for good

@@ -90,6 +90,13 @@ struct mt_engine {
   int chain_rollout_split = 0;  // ... and the rollout-kernel schedule of a chain's multi-step launches
   int multi_k = 1;              // mt_rollout: steps per launch on small shards (rollout kernels), 1 = one launch per step
   bool rollout_early = true;    // ... with the rollout kernels' RPF prologue (first step under the state loads; static tables)
+  // The episode boundary folded into mt_rollout's multi-step launches (kernels.h RolloutArgs):
+  bool defer_reset = true;      // mt_reset_random on such a handle is DEFERRED into the first launch of the next mt_rollout
+  bool reset_pending = false;   // ... one is waiting: every other entry point flushes it first (MT_ENTER, flush_pending_reset)
+  uint64_t pend_seed = 0;
+  uint32_t pend_episode = 0;
+  bool snap_in_rollout = true;  // the last launch of an mt_rollout call also stores the returns to the gather's snapshot row
+  bool snap_valid = false;      // ... it did, and nothing has touched the returns since: mt_gather_returns_begin skips its copy
   std::string overrides;        // the MT_* overrides choose_dispatch saw ("NAME=value,...")
   std::string describe;         // mt_describe_dispatch's text
   hipStream_t chain_streams[kMaxChains] = {nullptr, nullptr, nullptr, nullptr};  // [0] unused: chain 0 runs on `stream`
@@ -149,6 +156,8 @@ inline dim3 grid_for(int64_t n) { return dim3((unsigned)((n + kBlock - 1) / kBlo
 
 // engine.hip: the handle's stream waits for everything the chain streams still carry (no-op when not forked)
 int join_chains(mt_handle h);
+// engine.hip: a full reset that mt_reset_random deferred into the next mt_rollout is launched now (no-op without one)
+int flush_pending_reset(mt_handle h);
 
 }  // namespace mt
 
@@ -170,14 +179,20 @@ int join_chains(mt_handle h);
   return mt::fail(h, MT_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(mt_guard__.error()))
 
 // Entry of every call that touches the handle's device state as a whole: make the handle's device current and fold the
-// chains back into the handle's stream.  (mt_rollout and mt_reset_random, which work per chain, use MT_ON_DEVICE.)
-#define MT_ENTER(h)                      \
-  MT_ON_DEVICE(h, (h)->cfg.device);      \
-  do {                                   \
-    if ((h)->forked) {                   \
-      int rcj__ = mt::join_chains(h);    \
-      if (rcj__ != MT_OK) return rcj__;  \
-    }                                    \
+// chains back into the handle's stream, and launch a reset that was deferred into the next mt_rollout.  (mt_rollout and
+// mt_reset_random, which work per chain and know about deferred resets, use MT_ON_DEVICE.)
+#define MT_ENTER(h)                              \
+  MT_ON_DEVICE(h, (h)->cfg.device);              \
+  do {                                           \
+    (h)->snap_valid = false;                     \
+    if ((h)->forked) {                           \
+      int rcj__ = mt::join_chains(h);            \
+      if (rcj__ != MT_OK) return rcj__;          \
+    }                                            \
+    if ((h)->reset_pending) {                    \
+      int rcf__ = mt::flush_pending_reset(h);    \
+      if (rcf__ != MT_OK) return rcf__;          \
+    }                                            \
   } while (0)
 
 // comm.hip

@@ -1277,6 +1277,39 @@ __device__ __forceinline__ void draw_targets_wave(uint64_t seed, uint64_t env0, 
   __builtin_amdgcn_wave_barrier();  // a lane's column was written by other lanes of its wave
 }
 
+// The draw of an env that is spread over L lanes of a wave (lane = q * (64 / L) + e: reset_split_kernel, rollout_split_kernel):
+// sub-lane q evaluates blocks q, q + L, q + 2 L, ...; in every round the accepted candidates are numbered in block order across
+// the env's sub-lanes (their counts travel by shuffle), so the K targets handed to `put(k, x, y, z)` -- by whichever sub-lane
+// found them -- are exactly the first K accepted candidates of draw_targets' sequential order: the same bits.  Every sub-lane of
+// the env must call it (`go` = the env wants targets; equal in all of them, so they leave the loop together).
+template <int L, class Put>
+__device__ __forceinline__ void draw_targets_split(uint64_t seed, uint64_t env_id, uint32_t episode, bool go, int K, float radius,
+                                                   uint32_t q, uint32_t e, Put&& put) {
+  constexpr int EPW = 64 / L;
+  int cnt = go ? 0 : K;
+  for (uint32_t round = 0; round < 2048u / L && cnt < K; ++round) {
+    const u32x4 w = stream_block(seed, env_id, kTagTarget, episode, round * L + q);
+    float x0, y0, z0, x1, y1, z1;
+    const bool a0 = target_candidate<0>(w, radius, x0, y0, z0);
+    const bool a1 = target_candidate<1>(w, radius, x1, y1, z1);
+    const int mine = (a0 ? 1 : 0) + (a1 ? 1 : 0);
+    int before = 0, total = 0;
+#pragma unroll
+    for (int qq = 0; qq < L; ++qq) {
+      const int c = __shfl(mine, qq * EPW + (int)e);
+      total += c;
+      before += (qq < (int)q) ? c : 0;
+    }
+    const int k0 = cnt + before;
+    if (a0 && k0 < K) put(k0, x0, y0, z0);
+    const int k1 = k0 + (a0 ? 1 : 0);
+    if (a1 && k1 < K) put(k1, x1, y1, z1);
+    cnt += total;
+  }
+  if (q == 0)
+    for (; cnt < K; ++cnt) put(cnt, 0.f, 0.f, 0.5f * radius);  // unreachable in practice, as in draw_targets
+}
+
 template <int D, bool RANDOM, bool ONLY_DONE>
 __global__ __launch_bounds__(kBlock) void reset_kernel(const StepArgs a, float radius) {
   const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
@@ -1389,28 +1422,7 @@ __global__ __launch_bounds__(kBlock) void reset_split_kernel(const StepArgs a, f
     cell[EPB] = y;
     cell[2 * EPB] = z;
   };
-  int cnt = go ? 0 : K;  // the same in all sub-lanes of an env, so they leave the loop together
-  for (uint32_t round = 0; round < 2048u / L && cnt < K; ++round) {
-    const u32x4 w = stream_block(seed, env_id, kTagTarget, episode, round * L + q);
-    float x0, y0, z0, x1, y1, z1;
-    const bool a0 = target_candidate<0>(w, radius, x0, y0, z0);
-    const bool a1 = target_candidate<1>(w, radius, x1, y1, z1);
-    const int mine = (a0 ? 1 : 0) + (a1 ? 1 : 0);
-    int before = 0, total = 0;
-#pragma unroll
-    for (int qq = 0; qq < L; ++qq) {
-      const int c = __shfl(mine, qq * EPW + (int)e);
-      total += c;
-      before += (qq < (int)q) ? c : 0;
-    }
-    const int k0 = cnt + before;
-    if (a0 && k0 < K) put(k0, x0, y0, z0);
-    const int k1 = k0 + (a0 ? 1 : 0);
-    if (a1 && k1 < K) put(k1, x1, y1, z1);
-    cnt += total;
-  }
-  if (q == 0)
-    for (; cnt < K; ++cnt) put(cnt, 0.f, 0.f, 0.5f * radius);  // unreachable in practice, as in draw_targets
+  draw_targets_split<L>(seed, env_id, episode, go, K, radius, q, e, put);
   __builtin_amdgcn_wave_barrier();  // the columns were written by the env's sub-lanes; a wave only touches its own
   if (live && go)
     for (int r = (int)q; r < 3 * K; r += L) (a.points + (int64_t)r * ld)[i] = col[r * EPB];
@@ -1459,6 +1471,16 @@ struct RolloutArgs {
   uint32_t step0;
   uint32_t auto_reset;
   float radius;
+  // Episode boundary folded into the launch (mt_rollout's multi-step form, engine.hip):
+  //   reset_first : the launch BEGINS with the full random reset of every env that mt_reset_random(reset seed, reset_episode)
+  //                 deferred to it -- last_return <- return, zero pose, all targets alive, episode index, targets drawn from
+  //                 the (seed, env, episode) stream in draw_targets' sequential order: reset_kernel<.., RANDOM, false>'s
+  //                 state, bit for bit -- instead of loading pose / alive mask / return / targets: no reset launch, no
+  //                 re-fetch of what it would have written
+  //   snap        : the launch ENDS by storing every env's return to this row as well (the snapshot the overlapped return
+  //                 gather would otherwise take with a launch of its own behind it), or NULL
+  uint32_t reset_first, reset_episode, reset_seed_lo, reset_seed_hi;
+  float* snap;
 };
 
 //   RPF : prologue form.  0: the state and all targets are loaded (targets straight into LDS) before the first step starts
@@ -1486,21 +1508,34 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(const StepArgs a, const
   LaneOffset<true> o4{i * 4u}, o1{i};
   // (threads past the end: with a table and RPF they stay until the barrier -- their loads stay inside the rows, which are
   // ld >= round_up(n, 256) long, and the launch covers the batch or a 256-aligned range of it -- and leave right behind it)
-  if (!(kTable && RPF) && i >= a.n) return;
+  // (... and with a reset folded into the launch every lane of a wave takes part in the wave-cooperative draw below)
+  const bool stay = (kTable && RPF) || r.reset_first != 0;
+  if (!stay && i >= a.n) return;
   const int64_t ld = a.ld;
   const uint64_t seed = ((uint64_t)a.seed_hi << 32) | a.seed_lo;
   const uint64_t env_id = (uint64_t)(a.env_base + i);
   float* col = tile + threadIdx.x;
+  __shared__ uint8_t draw_slots[kBlock / 64][64];  // draw_targets_wave's scratch (used by launches with reset_first only)
 
+  const uint32_t all_alive = (a.K >= 32) ? 0xFFFFFFFFu : ((1u << a.K) - 1u);
+  const bool fresh = r.reset_first != 0;  // (wave-uniform: a launch argument)
   float g[D];
 #pragma unroll
-  for (int j = 0; j < D; ++j) g[j] = ldr(a.goals + j * ld, o4);
-  uint32_t am = ldr(a.alive, o4);
+  for (int j = 0; j < D; ++j) g[j] = fresh ? 0.f : ldr(a.goals + j * ld, o4);
+  uint32_t am = fresh ? all_alive : ldr(a.alive, o4);
   float total = ldr(a.total_reward, o4);
-  uint32_t episode = r.auto_reset ? ldr(a.episodes, o4) : 0u;
-  bool ended = false, dirty = false;
+  uint32_t episode = fresh ? r.reset_episode : (r.auto_reset ? ldr(a.episodes, o4) : 0u);
+  bool ended = fresh, dirty = fresh;  // a fresh episode writes its episode index and its targets back at the end
   float tx[RPF ? RPF : 1][3];
-  if (RPF) {
+  if (fresh) {
+    const bool mine = i < a.n;  // (threads past the end help with the draw and stay for the barrier, nothing else)
+    if (mine) str(a.last_return, o4, total);  // what reset_kernel<.., RANDOM, false> keeps of the episode that ends here
+    total = 0.f;
+    const uint32_t lane = threadIdx.x & 63u;
+    draw_targets_wave(((uint64_t)r.reset_seed_hi << 32) | r.reset_seed_lo, (uint64_t)(a.env_base + (i - lane)), episode, mine, a.K, r.radius,
+                      tile + (threadIdx.x - lane), draw_slots[threadIdx.x >> 6]);
+    if (!(kTable && RPF) && !mine) return;
+  } else if (RPF) {
 #pragma unroll
     for (int k = 0; k < RPF; ++k)
       if (k < a.K) {
@@ -1510,7 +1545,6 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(const StepArgs a, const
   } else {
     for (int k = 0; k < 3 * a.K; ++k) col[k * kBlock] = ldr(a.points + (int64_t)k * ld, o4);
   }
-  const uint32_t all_alive = (a.K >= 32) ? 0xFFFFFFFFu : ((1u << a.K) - 1u);
   PoseCache<D> pose;        // sines / cosines and frame heights of the pose the next step starts from
   bool pose_valid = false;  // nothing known about the pose loaded from memory
 
@@ -1585,13 +1619,15 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(const StepArgs a, const
     const float zmin = route_kinematics<Tbl, 0, true, kTable>(t, a.S, a.inv_sm1, g, act, el, e, &pose, false, trig,
                                                               (a.flags & kFlagWholeGoals) != 0);
     pose_valid = true;
+    if (!fresh) {  // (a fresh episode's targets were drawn straight into LDS)
 #pragma unroll
-    for (int k = 0; k < RPF; ++k)
-      if (k < a.K) {
+      for (int k = 0; k < RPF; ++k)
+        if (k < a.K) {
 #pragma unroll
-        for (int q = 0; q < 3; ++q) col[(3 * k + q) * kBlock] = tx[k][q];
-      }
-    for (int k = 3 * RPF; k < 3 * a.K; ++k) col[k * kBlock] = ldr(a.points + (int64_t)k * ld, o4);
+          for (int q = 0; q < 3; ++q) col[(3 * k + q) * kBlock] = tx[k][q];
+        }
+      for (int k = 3 * RPF; k < 3 * a.K; ++k) col[k * kBlock] = ldr(a.points + (int64_t)k * ld, o4);
+    }
     finish_step(act, el, e, zmin);
     s = 1;
   }
@@ -1608,6 +1644,7 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(const StepArgs a, const
   for (int j = 0; j < D; ++j) str(a.goals + j * ld, o4, g[j]);
   str(a.alive, o4, am);
   str(a.total_reward, o4, total);
+  if (r.snap) str(r.snap, o4, total);
   if (ended) str(a.episodes, o4, episode);
   if (dirty)
     for (int k = 0; k < 3 * a.K; ++k) str(a.points + (int64_t)k * ld, o4, col[k * kBlock]);
@@ -1655,15 +1692,28 @@ __global__ __launch_bounds__(kBlock) void rollout_split_kernel(const StepArgs a,
   float* col = tile + (threadIdx.x >> 6) * EPW + lane % EPW;
   const bool backward = (q & 1u) != 0;
 
+  const uint32_t all_alive = (a.K >= 32) ? 0xFFFFFFFFu : ((1u << a.K) - 1u);
+  const bool fresh = r.reset_first != 0;  // (wave-uniform: a launch argument; see RolloutArgs)
   float g[D];
 #pragma unroll
-  for (int j = 0; j < D; ++j) g[j] = (a.goals + j * ld)[i];
-  uint32_t am = a.alive[i];
+  for (int j = 0; j < D; ++j) g[j] = fresh ? 0.f : (a.goals + j * ld)[i];
+  uint32_t am = fresh ? all_alive : a.alive[i];
   float total = a.total_reward[i];
-  uint32_t episode = r.auto_reset ? a.episodes[i] : 0u;
-  bool ended = false, dirty = false;
+  uint32_t episode = fresh ? r.reset_episode : (r.auto_reset ? a.episodes[i] : 0u);
+  bool ended = fresh, dirty = fresh;
   float tx[PFS ? PFS : 1][3];
-  if (RPF) {  // this sub-lane's first targets into registers (target index p = q + L * m)
+  if (fresh) {  // the env's sub-lanes share the draw (reset_split_kernel's), whoever finds a target parks it in the env's column
+    if (live && q == 0) a.last_return[i] = total;
+    total = 0.f;
+    draw_targets_split<L>(((uint64_t)r.reset_seed_hi << 32) | r.reset_seed_lo, env_id, episode, true, a.K, r.radius, q, lane % EPW,
+                          [&](int k, float x, float y, float z) {
+                            float* pk = col + 3 * k * EPB;
+                            pk[0] = x;
+                            pk[EPB] = y;
+                            pk[2 * EPB] = z;
+                          });
+    __builtin_amdgcn_wave_barrier();  // a target's cells may have been written by another sub-lane of the env (same wave)
+  } else if (RPF) {  // this sub-lane's first targets into registers (target index p = q + L * m)
 #pragma unroll
     for (int m = 0; m < PFS; ++m) {
       const int p = (int)q + L * m;
@@ -1680,7 +1730,6 @@ __global__ __launch_bounds__(kBlock) void rollout_split_kernel(const StepArgs a,
       for (int c = 0; c < 3; ++c) col[(3 * p + c) * EPB] = (row + c * ld)[i];
     }
   }
-  const uint32_t all_alive = (a.K >= 32) ? 0xFFFFFFFFu : ((1u << a.K) - 1u);
   PoseCache<D> pose;
   bool pose_valid = false;
 
@@ -1765,18 +1814,20 @@ __global__ __launch_bounds__(kBlock) void rollout_split_kernel(const StepArgs a,
     const float zmin = route_kinematics_split<Tbl, L, true, kTable>(t, a.S, a.inv_sm1, g, act, backward, el, e, &pose, false, trig,
                                                                     (a.flags & kFlagWholeGoals) != 0);
     pose_valid = true;
+    if (!fresh) {  // (a fresh episode's targets were drawn straight into LDS)
 #pragma unroll
-    for (int m = 0; m < PFS; ++m) {
-      const int p = (int)q + L * m;
-      if (p < a.K) {
+      for (int m = 0; m < PFS; ++m) {
+        const int p = (int)q + L * m;
+        if (p < a.K) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) col[(3 * p + c) * EPB] = tx[m][c];
+          for (int c = 0; c < 3; ++c) col[(3 * p + c) * EPB] = tx[m][c];
+        }
       }
-    }
-    for (int p = (int)q + L * PFS; p < a.K; p += L) {
-      const float* row = a.points + (int64_t)(3 * p) * ld;
+      for (int p = (int)q + L * PFS; p < a.K; p += L) {
+        const float* row = a.points + (int64_t)(3 * p) * ld;
 #pragma unroll
-      for (int c = 0; c < 3; ++c) col[(3 * p + c) * EPB] = (row + c * ld)[i];
+        for (int c = 0; c < 3; ++c) col[(3 * p + c) * EPB] = (row + c * ld)[i];
+      }
     }
     finish_step(act, el, e, zmin);
     s = 1;
@@ -1795,6 +1846,7 @@ __global__ __launch_bounds__(kBlock) void rollout_split_kernel(const StepArgs a,
     for (int j = 0; j < D; ++j) (a.goals + j * ld)[i] = g[j];
     a.alive[i] = am;
     a.total_reward[i] = total;
+    if (r.snap) r.snap[i] = total;
     if (ended) a.episodes[i] = episode;
   }
   if (live && dirty)

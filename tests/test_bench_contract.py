@@ -37,7 +37,8 @@ def test_bench_prints_one_contract_line():
     # fifth of the state traffic (8 D + 12 K + 16 B per launch): achieved = those bytes / the device time of one step;
     # SURVEY's own 249-byte figure beside it
     assert r["steps_per_kernel_launch"] == 5.0 and r["launches_per_step"] == 1 and r["envs_per_launch"] == 262144
-    assert d["config"]["dispatch"]["rollout"] == {"form": "multi_step", "steps_per_launch": 5, "graph": False, "lanes_per_env": 1, "chains": 1}
+    assert d["config"]["dispatch"]["rollout"] == {"form": "multi_step", "steps_per_launch": 5, "graph": False, "lanes_per_env": 1, "chains": 1,
+                                                "absorbs_reset": True, "writes_snapshot": True}
     assert "5 steps per launch" in r["kernel"]
     moved = 101 + 132 / 5
     assert r["bytes_per_env_step"] == pytest.approx(moved) and r["bytes_per_env_step_survey_model"] == 249

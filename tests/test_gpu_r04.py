@@ -138,9 +138,11 @@ def test_rollout_default_dispatch_by_size(m, monkeypatch):
     # 131 072 (1 M over 8 GPUs) and 65 536 (configs[1]) = five steps per launch, two lanes per env
     assert seen[1048576]["chains"] == {"count": 2, "span": 524288, "lazy": True, "lanes_per_env": 1, "prefetch": True,
                                        "flat": True, "blocks_per_cu": 5}
-    assert seen[131072]["rollout"] == {"form": "multi_step", "steps_per_launch": 5, "graph": False, "lanes_per_env": 2, "chains": 1}
+    assert seen[131072]["rollout"] == {"form": "multi_step", "steps_per_launch": 5, "graph": False, "lanes_per_env": 2, "chains": 1, "absorbs_reset": True,
+                                       "writes_snapshot": True}
     # 163 840 .. 262 144: a two-chain handle (mt_step, resets while forked) whose mt_rollout is multi-step on ONE chain
-    assert seen[262144]["rollout"] == {"form": "multi_step", "steps_per_launch": 5, "graph": False, "lanes_per_env": 1, "chains": 1}
+    assert seen[262144]["rollout"] == {"form": "multi_step", "steps_per_launch": 5, "graph": False, "lanes_per_env": 1, "chains": 1, "absorbs_reset": True,
+                                       "writes_snapshot": True}
     assert seen[262144]["chains"]["count"] == 2 and seen[262400]["rollout"]["chains"] == 2
     assert seen[65536]["rollout"]["lanes_per_env"] == 2 and seen[32768]["rollout"]["lanes_per_env"] == 4
     # overrides are reported, and a 7-joint / runtime table / long route resolve differently
@@ -149,7 +151,8 @@ def test_rollout_default_dispatch_by_size(m, monkeypatch):
     e = m.StepEngine(100003, 7, dh_table=m.DH7_TABLE, radius=92.6)
     d = e.dispatch()
     assert d["overrides"] == "MT_CHAINS=3,MT_ROLLOUT_K=1" and d["table"] == "Dh7Table" and d["chains"]["count"] == 3
-    assert d["rollout"] == {"form": "chained_steps", "steps_per_launch": 1, "graph": True, "lanes_per_env": 2, "chains": 3}    # one cached graph per chain
+    assert d["rollout"] == {"form": "chained_steps", "steps_per_launch": 1, "graph": True, "lanes_per_env": 2, "chains": 3, "absorbs_reset": False,
+                            "writes_snapshot": False}    # one cached graph per chain
     e.close()
     monkeypatch.delenv("MT_ROLLOUT_K")
     monkeypatch.delenv("MT_CHAINS")
@@ -158,6 +161,118 @@ def test_rollout_default_dispatch_by_size(m, monkeypatch):
     assert d["table"] == "RtTable<5>" and d["trig"] == 1 and d["fused"]["usable"] is False
     assert d["rollout"]["form"] == "graph_replay" and d["rollout"]["steps_per_launch"] == 1 and d["step"]["lanes_per_env"] == 1
     e.close()
+
+
+# ---- the episode boundary folded into mt_rollout's multi-step launches --------------------------------------------------
+ALL_FIELDS = STATE_FIELDS + STEP_FIELDS + ("F_RETURN_RING",)
+
+
+def _episode_script(m, e, name, seed):
+    """Sequences around a full reset on a handle whose mt_rollout absorbs it; returns everything observable."""
+    import torch
+    out = {}
+    e.reset_random(seed, 0)
+    if name == "loop":                                   # the benchmark's episode loop: rollout, overlapped gather, reset, rollout
+        bufs = []
+        for ep in range(1, 4):
+            e.rollout(7 + ep, seed, 100 * ep)
+            e.gather_wait()
+            bufs.append(e.gather_begin())
+            e.reset_random(seed, ep)
+        e.rollout(6, seed, 900)
+        e.gather_wait(host=True)
+        e.sync()
+        out["gathered"] = [b.cpu().numpy().copy() for b in bufs]
+    elif name == "read_after_reset":                     # a getter right behind the reset: the reset's own state, complete
+        e.rollout(9, seed, 0)
+        e.reset_random(seed, 5)
+        out["after_reset"] = snapshot(m, e, ALL_FIELDS)
+        e.rollout(4, seed, 9)
+    elif name == "reset_twice":                          # the second reset overwrites what the first one kept
+        e.rollout(9, seed, 0)
+        e.reset_random(seed, 1)
+        e.reset_random(seed, 2)
+        e.rollout(3, seed, 9)
+    elif name == "staged_step":                          # the policy path behind a reset
+        e.rollout(5, seed, 0)
+        e.reset_random(seed, 1)
+        e.sample_actions(seed, 77)
+        e.step()
+        e.rollout(3, seed, 78)
+    elif name == "one_step_rollouts":                    # mt_rollout(1) cannot absorb the reset
+        e.rollout(5, seed, 0)
+        e.reset_random(seed, 1)
+        e.rollout(1, seed, 5)
+        e.rollout(1, seed, 6)
+        e.rollout(4, seed, 7)
+    elif name == "inplace_gather":                       # the exchange reads MT_F_LAST_RETURN, which the reset writes
+        e.rollout(8, seed, 0)
+        e.reset_random(seed, 1)
+        buf = e.gather_begin(field=m.lib.F_LAST_RETURN, snapshot=False)
+        e.rollout(5, seed, 8)
+        e.reset_random(seed, 2)                          # must wait for the exchange (in the kernel that absorbs it, too)
+        e.rollout(5, seed, 13)
+        e.gather_wait(host=True)
+        out["gathered"] = [buf.cpu().numpy().copy()]
+    elif name == "device_view":                          # a raw view handed out behind a reset sees the reset
+        e.rollout(6, seed, 0)
+        e.reset_random(seed, 1)
+        view = e.device_tensor(m.lib.F_TOTAL_REWARD)
+        e.sync()
+        out["view"] = view.clone().cpu().numpy()
+        e.rollout(4, seed, 6)
+    elif name == "fused_and_done":                       # other whole-batch calls behind the reset
+        e.rollout(6, seed, 0)
+        e.reset_random(seed, 1)
+        e.rollout_fused(5, seed, 6, auto_reset=True)
+        e.reset_random(seed, 2)
+        e.reset_done(seed)
+        e.rollout(5, seed, 11)
+    else:
+        raise AssertionError(name)
+    torch.cuda.synchronize()
+    out["final"] = snapshot(m, e, ALL_FIELDS)
+    return out
+
+
+@pytest.mark.parametrize("script", ["loop", "read_after_reset", "reset_twice", "staged_step", "one_step_rollouts", "inplace_gather",
+                                    "device_view", "fused_and_done"])
+@pytest.mark.parametrize("n,k,table_name,chains", [(131072, 7, "ref", None), (3001, 9, "ref", None), (200003, 7, "ref", None),
+                                                   (70001, 3, "dh7", None), (9001, 5, "rt5", None), (100003, 7, "ref", "2")])
+def test_reset_and_snapshot_folded_into_rollout_launches_equal_the_eager_forms(m, monkeypatch, n, k, table_name, chains, script):
+    """On a handle whose mt_rollout runs k steps per launch, mt_reset_random is deferred into the first launch of the next
+    mt_rollout (RolloutArgs::reset_first) and the last launch of an mt_rollout also writes the overlapped gather's snapshot
+    (RolloutArgs::snap).  Whatever is called in between -- getters, a second reset, staged steps, one-step rollouts, an
+    in-place exchange of MT_F_LAST_RETURN, raw device views, fused rollouts, reset_done -- must see exactly what the eager
+    reset kernel and the snapshot launch produce: every field, the gathered returns, the ring, bit for bit."""
+    table, radius = {"ref": (m.REF_DH_TABLE, 51.3), "dh7": (m.DH7_TABLE, 92.6), "rt5": (RT5, 25.0)}[table_name]
+    if chains:
+        monkeypatch.setenv("MT_CHAINS", chains)
+    monkeypatch.setenv("MT_DEFER_RESET", "0")
+    monkeypatch.setenv("MT_ROLLOUT_SNAP", "0")
+    ref = m.StepEngine(n, k, dh_table=table, radius=radius, pickup_tol=20.0, return_ring=3)
+    assert ref.dispatch()["rollout"]["absorbs_reset"] is False and ref.dispatch()["rollout"]["writes_snapshot"] is False
+    want = _episode_script(m, ref, script, 17)
+    ref.close()
+    monkeypatch.delenv("MT_DEFER_RESET")
+    monkeypatch.delenv("MT_ROLLOUT_SNAP")
+    eng = m.StepEngine(n, k, dh_table=table, radius=radius, pickup_tol=20.0, return_ring=3)
+    d = eng.dispatch()["rollout"]
+    assert d["form"] == "multi_step" and d["absorbs_reset"] is True and d["writes_snapshot"] is True
+    got = _episode_script(m, eng, script, 17)
+    eng.close()
+    assert_same(got["final"], want["final"], script)
+    if "after_reset" in want:
+        assert_same(got["after_reset"], want["after_reset"], script + ": right behind the reset")
+        a = want["after_reset"]
+        assert not a["F_GOALS"].any() and not a["F_TOTAL_REWARD"].any() and a["F_ALIVE"].all() and (a["F_EPISODES"] == 5).all()
+    for key in ("gathered",):
+        for x, y in zip(got.get(key, []), want.get(key, [])):
+            np.testing.assert_array_equal(x, y, err_msg=f"{script}: {key}")
+            assert np.abs(y).max() > 0
+    if "view" in want:
+        np.testing.assert_array_equal(got["view"], want["view"])
+        assert not want["view"][:n].any()
 
 
 # ---- mt_step per chain (VERDICT r3 #4) --------------------------------------------------------------------------------
