@@ -168,6 +168,11 @@ MT_API int mt_sync(mt_handle h);
  * over in device memory cannot be screened on the host: the reset kernel drops an unusable one (dead from the start,
  * coordinates zeroed) and counts it (mt_bad_action_count). */
 MT_API int mt_reset(mt_handle h, const float* points, int layout, int is_device);
+/* On a handle that runs on its OWN stream and whose mt_rollout runs several steps per launch (<= 262 144 envs), the launch of
+ * mt_reset_random is deferred: the next mt_rollout performs the reset as the prologue of its first launch (the same state,
+ * bit for bit, one launch and one round trip of the state less), and every other entry point -- mt_sync included, which is
+ * what the own-stream contract asks for before anything else looks at the state -- launches it first.  On a caller's stream
+ * (mt_set_stream) the reset is launched by the call itself, in stream order.  MT_DEFER_RESET=0 disables the deferral. */
 MT_API int mt_reset_random(mt_handle h, uint64_t seed, uint32_t episode);
 /* Re-arm only the envs whose done byte is 1: their return goes to MT_F_LAST_RETURN and into MT_F_RETURN_RING, their
  * episode index (MT_F_EPISODES) advances by one and keys the new targets (device RNG), pose and return are zeroed.

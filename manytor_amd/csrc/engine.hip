@@ -1170,8 +1170,12 @@ static int reset_random_impl(mt_handle h, uint64_t seed, uint32_t episode, int m
   // A full reset of a handle whose mt_rollout runs k steps per launch is DEFERRED into the first launch of the next
   // mt_rollout (RolloutArgs::reset_first: the same state, bit for bit, without the reset's launch and without re-fetching what
   // it would have written: an episode end of a 131 072-env shard goes from 20 to 6 us on the device, tools/episode_end_cost.py).
-  // Any other entry point launches it first (MT_ENTER).  Not while the chains are forked (the per-chain reset above).
-  if (mode == 1 && h->defer_reset && rollout_is_multi_step(h) && !h->forked) {
+  // Any other entry point launches it first (MT_ENTER).  Not while the chains are forked (the per-chain reset above), and
+  // only on the handle's OWN stream: there the contract already is "mt_sync before anything else looks at the state" (and
+  // mt_sync launches it); on a caller's stream the contract is stream order, and whatever the caller queues next without
+  // calling the library -- a replay of a graph captured from mt_step, a torch kernel on a view it holds -- has to find
+  // the reset done.
+  if (mode == 1 && h->defer_reset && rollout_is_multi_step(h) && !h->forked && h->stream == h->own_stream) {
     h->args.seed_lo = (uint32_t)seed;
     h->args.seed_hi = (uint32_t)(seed >> 32);
     h->args.major = episode;

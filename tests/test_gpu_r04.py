@@ -167,10 +167,12 @@ def test_rollout_default_dispatch_by_size(m, monkeypatch):
 ALL_FIELDS = STATE_FIELDS + STEP_FIELDS + ("F_RETURN_RING",)
 
 
-def _episode_script(m, e, name, seed):
+def _episode_script(m, e, name, seed, on_torch_stream=False):
     """Sequences around a full reset on a handle whose mt_rollout absorbs it; returns everything observable."""
     import torch
     out = {}
+    if on_torch_stream:
+        e.use_torch_stream()                             # stream order is the contract there: the reset is not deferred
     e.reset_random(seed, 0)
     if name == "loop":                                   # the benchmark's episode loop: rollout, overlapped gather, reset, rollout
         bufs = []
@@ -237,14 +239,18 @@ def _episode_script(m, e, name, seed):
 
 @pytest.mark.parametrize("script", ["loop", "read_after_reset", "reset_twice", "staged_step", "one_step_rollouts", "inplace_gather",
                                     "device_view", "fused_and_done"])
+@pytest.mark.parametrize("on_torch_stream", [False, True])
 @pytest.mark.parametrize("n,k,table_name,chains", [(131072, 7, "ref", None), (3001, 9, "ref", None), (200003, 7, "ref", None),
                                                    (70001, 3, "dh7", None), (9001, 5, "rt5", None), (100003, 7, "ref", "2")])
-def test_reset_and_snapshot_folded_into_rollout_launches_equal_the_eager_forms(m, monkeypatch, n, k, table_name, chains, script):
+def test_reset_and_snapshot_folded_into_rollout_launches_equal_the_eager_forms(m, monkeypatch, n, k, table_name, chains, script,
+                                                                               on_torch_stream):
     """On a handle whose mt_rollout runs k steps per launch, mt_reset_random is deferred into the first launch of the next
     mt_rollout (RolloutArgs::reset_first) and the last launch of an mt_rollout also writes the overlapped gather's snapshot
     (RolloutArgs::snap).  Whatever is called in between -- getters, a second reset, staged steps, one-step rollouts, an
     in-place exchange of MT_F_LAST_RETURN, raw device views, fused rollouts, reset_done -- must see exactly what the eager
-    reset kernel and the snapshot launch produce: every field, the gathered returns, the ring, bit for bit."""
+    reset kernel and the snapshot launch produce: every field, the gathered returns, the ring, bit for bit.  On a caller's
+    stream the reset is not deferred (stream order is the contract there; test_step_is_capturable_in_a_hip_graph replays a
+    captured step right behind a reset), the snapshot still rides along."""
     table, radius = {"ref": (m.REF_DH_TABLE, 51.3), "dh7": (m.DH7_TABLE, 92.6), "rt5": (RT5, 25.0)}[table_name]
     if chains:
         monkeypatch.setenv("MT_CHAINS", chains)
@@ -252,14 +258,14 @@ def test_reset_and_snapshot_folded_into_rollout_launches_equal_the_eager_forms(m
     monkeypatch.setenv("MT_ROLLOUT_SNAP", "0")
     ref = m.StepEngine(n, k, dh_table=table, radius=radius, pickup_tol=20.0, return_ring=3)
     assert ref.dispatch()["rollout"]["absorbs_reset"] is False and ref.dispatch()["rollout"]["writes_snapshot"] is False
-    want = _episode_script(m, ref, script, 17)
+    want = _episode_script(m, ref, script, 17, on_torch_stream)
     ref.close()
     monkeypatch.delenv("MT_DEFER_RESET")
     monkeypatch.delenv("MT_ROLLOUT_SNAP")
     eng = m.StepEngine(n, k, dh_table=table, radius=radius, pickup_tol=20.0, return_ring=3)
     d = eng.dispatch()["rollout"]
     assert d["form"] == "multi_step" and d["absorbs_reset"] is True and d["writes_snapshot"] is True
-    got = _episode_script(m, eng, script, 17)
+    got = _episode_script(m, eng, script, 17, on_torch_stream)
     eng.close()
     assert_same(got["final"], want["final"], script)
     if "after_reset" in want:
