@@ -162,6 +162,9 @@ struct DispatchPolicy {
   //   (4.78 / 5.88 us) but slower from an idle device over a 20-step segment (5.83 / 6.81) and slower at >= 196 608.
   int64_t multi_step_max = 262144;
   int multi_step_k = 5;
+  // the chained launch-per-step form of the large batches starts an episode with ONE step of the rollout kernel that carries
+  // the deferred reset as its prologue
+  bool fold_reset_into_chains = false;
   // the angle-addition recurrence is run (S - 1) / 2 rotations from each end of a route; beyond this many the per-pose
   // polynomial sincos kernels take over (drift: 12 rotations 3.3e-5 / 6.6e-5 in z on the 4- / 7-joint arm, 31 rotations
   // 8.6e-5 / 1.3e-4, outside the 1e-4 position tolerance)                                [tests/test_gpu_zmin.py]
@@ -300,6 +303,13 @@ static void choose_dispatch(mt_handle h) {
   if (env_int("MT_DEFER_RESET", &v)) {
     h->defer_reset = v != 0;
     seen("MT_DEFER_RESET");
+  }
+  // ... and, for the chained launch-per-step form of the large batches, as a one-step launch of the rollout kernel in front
+  // of each chain's step launches (profiles/r04_variants.md section 4)
+  h->defer_reset_chained = P.fold_reset_into_chains;
+  if (env_int("MT_DEFER_RESET_CHAINS", &v)) {
+    h->defer_reset_chained = v != 0;
+    seen("MT_DEFER_RESET_CHAINS");
   }
   h->snap_in_rollout = true;
   if (env_int("MT_ROLLOUT_SNAP", &v)) {
@@ -654,6 +664,15 @@ void launch_rollout(mt_handle h, const StepArgs& a, int split, const RolloutArgs
 // The rollout kernels implement the default trigonometry and the reference's frame rows only.
 bool fusable(mt_handle h) { return h->trig == 0 && !h->lds_table && !h->trace && !h->custom_frames; }
 
+// Does mt_rollout(n_steps >= 2) on this handle run k steps per launch through the rollout kernels right now?
+bool rollout_is_multi_step(mt_handle h) { return h->multi_k > 1 && fusable(h); }
+// Does it run as chains of one launch per step whose FIRST launch can be the rollout kernel with the reset as its prologue?
+bool chained_rollout_absorbs_reset(mt_handle h) {
+  const bool graph = h->graph_mode > 0 || (h->graph_mode < 0 && h->n <= h->graph_max);
+  return h->defer_reset_chained && !rollout_is_multi_step(h) && h->chains > 1 && h->lazy_chains && !h->trace && !graph && fusable(h);
+}
+
+
 int check_launch(mt_handle h, const char* what) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(h, MT_ERR_HIP, std::string(what) + " launch: " + hipGetErrorString(e));
@@ -1003,7 +1022,7 @@ const char* mt_describe_dispatch(mt_handle h) {
       "\",\"steps_per_launch\":" + num(multi ? h->multi_k : 1) + ",\"graph\":" + b(!multi && graph) +
       ",\"lanes_per_env\":" + num(std::max(1, multi ? ((h->chains > 1 && h->chains_forced) ? h->chain_rollout_split : h->rollout_split) : (rec ? (h->chains > 1 ? h->chain_split : h->split) : 0))) +
       ",\"chains\":" + num(multi && !h->chains_forced ? 1 : h->chains) +
-      ",\"absorbs_reset\":" + b(multi && h->defer_reset) + ",\"writes_snapshot\":" + b(multi && h->snap_in_rollout) + "}" +
+      ",\"absorbs_reset\":" + b(h->defer_reset && (multi || chained_rollout_absorbs_reset(h))) + ",\"writes_snapshot\":" + b(multi && h->snap_in_rollout) + "}" +
       ",\"fused\":{\"usable\":" + b(fusable(h)) + ",\"lanes_per_env\":" + num(h->rollout_split ? h->rollout_split : 1) + "}" +
       ",\"reset\":{\"lanes_per_env\":" + num(h->reset_split ? 4 : 1) + "}" +
       ",\"overrides\":\"" + h->overrides + "\"" +
@@ -1158,9 +1177,6 @@ int flush_pending_reset(mt_handle h) {
 
 extern "C" {
 
-// Does mt_rollout(n_steps >= 2) on this handle run k steps per launch through the rollout kernels right now?
-static bool rollout_is_multi_step(mt_handle h) { return h->multi_k > 1 && fusable(h); }
-
 static int reset_random_impl(mt_handle h, uint64_t seed, uint32_t episode, int mode) {
   MT_REQUIRE(nullptr, h != nullptr, "handle is NULL");
   MT_ON_DEVICE(h, h->cfg.device);
@@ -1175,7 +1191,8 @@ static int reset_random_impl(mt_handle h, uint64_t seed, uint32_t episode, int m
   // mt_sync launches it); on a caller's stream the contract is stream order, and whatever the caller queues next without
   // calling the library -- a replay of a graph captured from mt_step, a torch kernel on a view it holds -- has to find
   // the reset done.
-  if (mode == 1 && h->defer_reset && rollout_is_multi_step(h) && !h->forked && h->stream == h->own_stream) {
+  if (mode == 1 && h->defer_reset && h->stream == h->own_stream &&
+      ((rollout_is_multi_step(h) && !h->forked) || chained_rollout_absorbs_reset(h))) {
     h->args.seed_lo = (uint32_t)seed;
     h->args.seed_hi = (uint32_t)(seed >> 32);
     h->args.major = episode;
@@ -1552,7 +1569,8 @@ int mt_rollout(mt_handle h, int n_steps, uint64_t seed, uint32_t step_idx0) {
   int chains = n_steps >= 2 ? usable_chains(h) : 1;
   h->snap_valid = false;  // the returns are about to change
   const bool multi = n_steps >= 2 && rollout_is_multi_step(h);
-  if (h->reset_pending && !multi) {  // a deferred reset and a form that cannot absorb it: launch it now
+  const bool chained_fresh = h->reset_pending && !multi && chains > 1 && chained_rollout_absorbs_reset(h) && !rollout_uses_graph(h, n_steps);
+  if (h->reset_pending && !multi && !chained_fresh) {  // a deferred reset and a form that cannot absorb it: launch it now
     int rc = flush_pending_reset(h);
     if (rc) return rc;
   }
@@ -1669,9 +1687,20 @@ int mt_rollout(mt_handle h, int n_steps, uint64_t seed, uint32_t step_idx0) {
     if (rc) return rc;
     // chains enqueued round-robin step by step, so that no stream runs dry while the host is busy with another one
     hipStream_t root = h->stream;
+    const int64_t span = chain_span(h, chains);
+    h->reset_pending = false;
     for (int st = 0; st < n_steps; ++st)
       for (int c = 0; c < chains; ++c) {
         h->stream = c == 0 ? root : h->chain_streams[c];
+        const int64_t off = (int64_t)c * span;
+        if (chained_fresh && st == 0 && off < h->n) {
+          // the episode's first step: ONE step of the rollout kernel with the deferred reset as its prologue (the state of
+          // reset_kernel + step_kernel, bit for bit: no reset launch, no re-fetch of what it would have written)
+          (void)order_behind_inplace_gather(h, h->stream);  // (the in-kernel reset writes MT_F_LAST_RETURN)
+          const RolloutArgs r{1, step_idx0, 0u, h->cfg.radius, 1u, h->pend_episode, (uint32_t)h->pend_seed, (uint32_t)(h->pend_seed >> 32), nullptr};
+          launch_rollout(h, args_for_range(h, a, off, std::min(span, h->n - off)), 1, r, h->rollout_early);
+          continue;
+        }
         launch_chain(h, a, step_idx0 + (uint32_t)st, 1, chains, c);
       }
     h->stream = root;

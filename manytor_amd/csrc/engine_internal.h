@@ -91,6 +91,7 @@ struct mt_engine {
   int multi_k = 1;              // mt_rollout: steps per launch on small shards (rollout kernels), 1 = one launch per step
   bool rollout_early = true;    // ... with the rollout kernels' RPF prologue (first step under the state loads; static tables)
   // The episode boundary folded into mt_rollout's multi-step launches (kernels.h RolloutArgs):
+  bool defer_reset_chained = false;  // ... and into the first launch of each chain of the chained launch-per-step form
   bool defer_reset = true;      // mt_reset_random on such a handle is DEFERRED into the first launch of the next mt_rollout
   bool reset_pending = false;   // ... one is waiting: every other entry point flushes it first (MT_ENTER, flush_pending_reset)
   uint64_t pend_seed = 0;

@@ -281,6 +281,39 @@ def test_reset_and_snapshot_folded_into_rollout_launches_equal_the_eager_forms(m
         assert not want["view"][:n].any()
 
 
+@pytest.mark.parametrize("script", ["loop", "read_after_reset", "reset_twice", "staged_step", "one_step_rollouts", "inplace_gather",
+                                    "device_view", "fused_and_done"])
+@pytest.mark.parametrize("n,k,table_name,env", [(300007, 7, "ref", {}), (530000, 5, "dh7", {}),
+                                                (70001, 3, "ref", {"MT_CHAINS": "3", "MT_ROLLOUT_K": "1", "MT_GRAPH": "0"})])
+def test_reset_folded_into_the_first_launch_of_each_chain_equals_the_eager_form(m, monkeypatch, n, k, table_name, env, script):
+    """The chained launch-per-step form of the large batches (MT_DEFER_RESET_CHAINS=1): a deferred mt_reset_random becomes the
+    prologue of ONE step of the rollout kernel at the head of each chain's launches -- the same scripts, the same bits as the
+    eager per-chain reset kernels."""
+    table, radius = {"ref": (m.REF_DH_TABLE, 51.3), "dh7": (m.DH7_TABLE, 92.6)}[table_name]
+    for key, val in env.items():
+        monkeypatch.setenv(key, val)
+    monkeypatch.setenv("MT_DEFER_RESET", "0")
+    ref = m.StepEngine(n, k, dh_table=table, radius=radius, pickup_tol=20.0, return_ring=3)
+    assert ref.dispatch()["rollout"]["absorbs_reset"] is False and ref.dispatch()["rollout"]["form"] == "chained_steps"
+    want = _episode_script(m, ref, script, 23)
+    ref.close()
+    monkeypatch.delenv("MT_DEFER_RESET")
+    monkeypatch.setenv("MT_DEFER_RESET_CHAINS", "1")
+    eng = m.StepEngine(n, k, dh_table=table, radius=radius, pickup_tol=20.0, return_ring=3)
+    d = eng.dispatch()["rollout"]
+    assert d["form"] == "chained_steps" and d["graph"] is False and d["absorbs_reset"] is True
+    got = _episode_script(m, eng, script, 23)
+    eng.close()
+    assert_same(got["final"], want["final"], script)
+    if "after_reset" in want:
+        assert_same(got["after_reset"], want["after_reset"], script + ": right behind the reset")
+    for x, y in zip(got.get("gathered", []), want.get("gathered", [])):
+        np.testing.assert_array_equal(x, y, err_msg=f"{script}: gathered")
+        assert np.abs(y).max() > 0
+    if "view" in want:
+        np.testing.assert_array_equal(got["view"], want["view"])
+
+
 # ---- mt_step per chain (VERDICT r3 #4) --------------------------------------------------------------------------------
 def _policy_steps(m, e, torch, mode, seed, steps, on_torch_stream):
     """`steps` policy-in-the-loop steps; the actions reach the engine by `mode`."""
