@@ -240,9 +240,15 @@ class EpisodeLoop:
 
     reset_first = False         # experiment switch (--reset-before-gather), see _episode_end
 
-    def __init__(self, engine, seed, episode_len, fused=False, overlap=True, steps_per_launch=1):
+    def __init__(self, engine, seed, episode_len, fused=False, overlap=True, steps_per_launch=1, absorbs_reset=False):
         self.eng, self.seed, self.L, self.fused, self.overlap = engine, seed, int(episode_len), fused, overlap
         self.steps_per_launch = max(1, int(steps_per_launch))     # mt_rollout's k on small shards (engine.dispatch())
+        # mt_rollout absorbs a deferred reset into its first launch (dispatch().rollout.absorbs_reset): the timed loop then
+        # issues an episode's first launch -- reset prologue + `steps_per_launch` steps -- as a call of its own OUTSIDE the step
+        # laps (inside the region and its device timeline like everything else), so that the laps hold step launches only
+        # and agree with the kernel trace's average of the step kernel.  The launches are the ones one rollout call makes.
+        self.head_steps = self.steps_per_launch if (absorbs_reset and not fused) else 0
+        self.head_launches = 0      # episode-first launches issued outside the step laps (see head_steps)
         self.kernel_launches = 0    # kernel launches (per env range) behind the timed steps: ceil(segment / k), 1 per fused segment
         self.lap_steps = []         # steps inside every timed step lap, in lap order
         self.step = 0
@@ -300,6 +306,16 @@ class EpisodeLoop:
         done = launches = gathers = 0
         while done < count:
             seg = min(count - done, self.L - self.step % self.L)
+            if time_kernels and self.head_steps and self.step % self.L == 0 and seg > self.head_steps:
+                seg = self.head_steps
+                self.eng.rollout(seg, self.seed, self.step)          # the episode's first launch: reset + steps, unlapped
+                self.step += seg
+                done += seg
+                self.head_launches += 1
+                if self.step % self.L == 0:
+                    self._episode_end(time_kernels)
+                    gathers += 1
+                continue
             if time_kernels:
                 self.eng.lap_begin("step")      # HIP events on the engine's stream, no host synchronisation
             if self.fused:
@@ -389,7 +405,8 @@ def time_step_launches(m, n, table, radius, k, dev, seed, fused=False, steps=600
             else:
                 os.environ["MT_ROLLOUT_K"] = keep
     e = TimedEngine(raw)
-    loop = EpisodeLoop(e, seed, episode_len, fused=fused, overlap=False, steps_per_launch=rollout_steps_per_launch(raw))
+    loop = EpisodeLoop(e, seed, episode_len, fused=fused, overlap=False, steps_per_launch=rollout_steps_per_launch(raw),
+                       absorbs_reset=rollout_absorbs_reset(raw))
     t0 = time.perf_counter()
     while time.perf_counter() - t0 < 0.15:
         loop.run(4 * episode_len)
@@ -504,6 +521,14 @@ class Fabric:
         return bool(int(t.item()))
 
 
+def rollout_absorbs_reset(raw):
+    """Does mt_rollout on this engine take a deferred mt_reset_random into its first launch?  (mt_describe_dispatch)"""
+    try:
+        return bool(raw.dispatch()["rollout"]["absorbs_reset"])
+    except (AttributeError, KeyError):
+        return False
+
+
 def rollout_steps_per_launch(raw):
     """k of mt_rollout on this engine (1 = one launch per step), from mt_describe_dispatch."""
     try:
@@ -521,7 +546,8 @@ def measure(fab, raw, n_total, steps, warmup, episode_len, seed, fused=False, ov
     exchange): `region_device_ms`, max over ranks, median.  Returns a dict of raw numbers."""
     eng = TimedEngine(raw)
     L = max(1, min(episode_len, steps))                         # >= 1 gather inside every timed region
-    loop = EpisodeLoop(eng, seed, L, fused=fused, overlap=overlap, steps_per_launch=rollout_steps_per_launch(raw))
+    loop = EpisodeLoop(eng, seed, L, fused=fused, overlap=overlap, steps_per_launch=rollout_steps_per_launch(raw),
+                       absorbs_reset=rollout_absorbs_reset(raw))
     prewarm = 0
     fab.fence(raw)
     t0 = time.perf_counter()
@@ -569,7 +595,8 @@ def measure(fab, raw, n_total, steps, warmup, episode_len, seed, fused=False, ov
             "repeats": reps, "prewarm": prewarm, "episode_len": L, "value": n_total * steps / elapsed,
             "region_device_ms": dev_s * 1e3, "device_ms_per_step": dev_s * 1e3 / steps,
             "value_device_timeline": n_total * steps / max(dev_s, 1e-12),
-            "steps_per_kernel_launch": launches / max(1, loop.kernel_launches)}
+            "steps_per_kernel_launch": launches / max(1, loop.kernel_launches),
+            "episode_first_launches_outside_laps": loop.head_launches, "episode_first_launch_steps": loop.head_steps}
 
 
 def self_launch(argv, gpus, dry_run=False, timeout_s=1800.0, script=None):
@@ -941,6 +968,8 @@ def main():
                            kernel_name + " (action drawn in-kernel)"),
                 "bytes_per_env_step": moved, "avg_kernel_us": r["step_us"], "avg_kernel_us_max_region": r["step_us_max_region"],
                 "steps_timed": r["launches"],
+                "episode_first_launches_outside_laps": r["episode_first_launches_outside_laps"],
+                "episode_first_launch_steps": r["episode_first_launch_steps"],
                 "steps_per_kernel_launch": spl,
                 "launches_per_step": chains, "envs_per_launch": envs_per_launch,
                 "bytes_per_launch": moved * spl * envs_per_launch, "bytes_per_step": moved * n_local,
@@ -959,7 +988,10 @@ def main():
                         "new goals), and -- when mt_rollout runs k steps per launch (steps_per_kernel_launch > 1: small shards) "
                         "-- the state rows once per launch instead of once per step; *_survey_model are the same time with "
                         "SURVEY's own 249-byte figure.  avg_kernel_us = device time of ONE STEP of this rank's envs by HIP "
-                        "events around the step launches, fork and join of the chains included.  With launches_per_step = 2 a "
+                        "events around the step launches, fork and join of the chains included; where mt_rollout absorbs the "
+                        "episode's reset into its first launch (config.dispatch.rollout.absorbs_reset), that launch -- reset "
+                        "prologue + episode_first_launch_steps steps, another kernel -- is issued outside these laps (inside "
+                        "the region and its device timeline).  With launches_per_step = 2 a "
                         "step is two CONCURRENT launches of envs_per_launch envs on two streams: rocprofv3's per-launch "
                         "average is then the duration of each of two overlapping kernels, not half a step; the union of "
                         "their intervals per step (tools/trace_summary.py --union) corresponds to avg_kernel_us",

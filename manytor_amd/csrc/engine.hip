@@ -1566,10 +1566,12 @@ int mt_rollout(mt_handle h, int n_steps, uint64_t seed, uint32_t step_idx0) {
   MT_ON_DEVICE(h, h->cfg.device);  // per-chain call: joins only where it has to (below)
   // several independent chains of launches (env ranges on separate streams) where that pays; a caller who is capturing
   // the handle's stream gets the plain single-stream sequence
-  int chains = n_steps >= 2 ? usable_chains(h) : 1;
+  // (a call that finds a deferred reset takes the form that absorbs it even for a single step)
+  int chains = (n_steps >= 2 || h->reset_pending) ? usable_chains(h) : 1;
   h->snap_valid = false;  // the returns are about to change
-  const bool multi = n_steps >= 2 && rollout_is_multi_step(h);
+  const bool multi = (n_steps >= 2 || h->reset_pending) && rollout_is_multi_step(h);
   const bool chained_fresh = h->reset_pending && !multi && chains > 1 && chained_rollout_absorbs_reset(h) && !rollout_uses_graph(h, n_steps);
+  if (n_steps < 2 && !multi && !chained_fresh) chains = 1;
   if (h->reset_pending && !multi && !chained_fresh) {  // a deferred reset and a form that cannot absorb it: launch it now
     int rc = flush_pending_reset(h);
     if (rc) return rc;
@@ -1925,7 +1927,7 @@ int mt_device_ptr(mt_handle h, int field, void** ptr, int64_t* rows, int64_t* ld
 // ---- timing -----------------------------------------------------------------------------------
 int mt_timer_start(mt_handle h) {
   MT_REQUIRE(nullptr, h != nullptr, "handle is NULL");
-  MT_ENTER(h);
+  MT_ENTER_TIMER(h);
   MT_HIP(h, hipEventRecord(h->ev0, h->stream));
   return MT_OK;
 }
@@ -1933,7 +1935,7 @@ int mt_timer_start(mt_handle h) {
 int mt_timer_stop(mt_handle h, float* elapsed_ms) {
   MT_REQUIRE(nullptr, h != nullptr, "handle is NULL");
   MT_REQUIRE(h, elapsed_ms != nullptr, "elapsed_ms is NULL");
-  MT_ENTER(h);
+  MT_ENTER_TIMER(h);
   MT_HIP(h, hipEventRecord(h->ev1, h->stream));
   MT_HIP(h, hipEventSynchronize(h->ev1));
   MT_HIP(h, hipEventElapsedTime(elapsed_ms, h->ev0, h->ev1));
@@ -2007,12 +2009,30 @@ static int lap_event(mt_handle h, hipStream_t stream, uint32_t* index) {
 int mt_timer_lap_begin(mt_handle h) {
   MT_REQUIRE(nullptr, h != nullptr, "handle is NULL");
   if (h->lap_open) return fail(h, MT_ERR_STATE, "mt_timer_lap_begin: a lap is already open");
-  MT_ENTER(h);  // a lap starts on the handle's stream with everything before it folded in
-  mt_engine::LapRec rec{0, 0, 0};
-  int rc = lap_reserve(h, 1 + (size_t)mt_engine::kMaxChains);  // the whole lap's events exist before it begins
+  // A lap starts behind everything queued before it.  While the chains are forked on the handle's own stream they stay
+  // forked: one begin event per chain, the lap runs from the earliest of them to the latest end event (a join here would
+  // put two cross-stream dependencies into the timed work for the sake of the stopwatch: 20 us per episode at 1 M arms).
+  const bool per_chain = h->forked && h->lazy_chains && h->stream == h->own_stream;
+  if (per_chain) {
+    MT_ON_DEVICE(h, h->cfg.device);
+    int rcf = flush_pending_reset(h);  // (per chain as well while forked)
+    if (rcf) return rcf;
+  } else {
+    MT_ENTER(h);
+  }
+  mt_engine::LapRec rec{0, 1, 0, 0};
+  int rc = lap_reserve(h, 2 * (size_t)mt_engine::kMaxChains);  // the whole lap's events exist before it begins
   if (rc) return rc;
   rc = lap_event(h, h->stream, &rec.begin);
   if (rc) return rc;
+  if (per_chain && h->forked)
+    for (int c = 1; c < h->chains; ++c) {
+      if (!h->chain_streams[c] || (int64_t)c * chain_span(h, h->chains) >= h->n) continue;
+      uint32_t idx;
+      rc = lap_event(h, h->chain_streams[c], &idx);  // consecutive indices: begin, begin + 1, ...
+      if (rc) return rc;
+      ++rec.n_begin;
+    }
   h->lap_recs.push_back(rec);
   h->lap_open = true;
   return MT_OK;
@@ -2038,14 +2058,16 @@ int mt_timer_lap_end(mt_handle h) {
   return MT_OK;
 }
 
-// milliseconds of lap `rec`: from its begin to the latest of its end events
+// milliseconds of lap `rec`: from the earliest of its begin events to the latest of its end events
 static int lap_ms(mt_handle h, const mt_engine::LapRec& rec, float* ms) {
   float best = 0.f;
   for (uint32_t k = 0; k < rec.n_end; ++k) {
-    float v = 0.f;
     MT_HIP(h, hipEventSynchronize(h->lap_events[rec.end0 + k]));
-    MT_HIP(h, hipEventElapsedTime(&v, h->lap_events[rec.begin], h->lap_events[rec.end0 + k]));
-    best = v > best ? v : best;
+    for (uint32_t b = 0; b < rec.n_begin; ++b) {
+      float v = 0.f;
+      MT_HIP(h, hipEventElapsedTime(&v, h->lap_events[rec.begin + b], h->lap_events[rec.end0 + k]));
+      best = v > best ? v : best;
+    }
   }
   *ms = best;
   return MT_OK;

@@ -27,7 +27,7 @@ struct mt_engine {
   // mt_timer_lap_*: a lap = one begin event on the handle's stream + one end event per stream that carried work of the lap
   // (the handle's stream, and the chain streams while mt_rollout's chains are forked); its time = begin -> the latest end
   struct LapRec {
-    uint32_t begin, end0, n_end;  // indices into lap_events
+    uint32_t begin, n_begin, end0, n_end;  // indices into lap_events: begin .. begin + n_begin - 1, end0 .. end0 + n_end - 1
   };
   std::vector<hipEvent_t> lap_events;  // event pool, grown on demand
   size_t lap_events_used = 0;
@@ -193,6 +193,17 @@ int flush_pending_reset(mt_handle h);
     if ((h)->reset_pending) {                    \
       int rcf__ = mt::flush_pending_reset(h);    \
       if (rcf__ != MT_OK) return rcf__;          \
+    }                                            \
+  } while (0)
+
+// The timers' entry: the join of MT_ENTER without the rest.  A deferred reset is work of whatever FOLLOWS the timer call --
+// launching it here would put it in front of the region's start event, outside the timeline it belongs to.
+#define MT_ENTER_TIMER(h)                        \
+  MT_ON_DEVICE(h, (h)->cfg.device);              \
+  do {                                           \
+    if ((h)->forked) {                           \
+      int rcj__ = mt::join_chains(h);            \
+      if (rcj__ != MT_OK) return rcj__;          \
     }                                            \
   } while (0)
 

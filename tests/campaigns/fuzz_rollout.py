@@ -4,7 +4,7 @@ arm (reference, 7-joint, random table; sometimes with other observation / pickup
 (up to the sizes where mt_rollout runs as chains), and a random schedule forced through the environment -- MT_CHAINS 1..4,
 MT_GRAPH 0 / 1, MT_TRIG_TABLE 0 / 1, MT_SPLIT 0 / 2 / 4, MT_PREFETCH 0 / 1, MT_RESET_SPLIT 0 / 1, and (round 4) MT_ROLLOUT_K 1 .. 9 with
 either prologue of the rollout kernels (MT_ROLLOUT_EARLY), the reset deferred into / the gather's snapshot written by the multi-step
-launches or not (MT_DEFER_RESET, MT_ROLLOUT_SNAP), plus staged-action steps (mt_sample_actions + mt_step: per chain on
+launches or not (MT_DEFER_RESET, MT_ROLLOUT_SNAP; MT_DEFER_RESET_CHAINS for the chained launch-per-step form), plus staged-action steps (mt_sample_actions + mt_step: per chain on
 multi-chain handles) mixed into the plan.  Every case is checked two ways:
   * bit for bit against the plainest schedule of the same library (one chain, no graph, no table, one env per lane), all
     state and step-output fields, after a mix of rollouts, fused rollouts and reset_done calls;
@@ -29,7 +29,7 @@ from oracle import philox_ref as px  # noqa: E402
 FIELDS = ("F_GOALS", "F_ALIVE", "F_TOTAL_REWARD", "F_POINTS", "F_EPISODES", "F_LAST_RETURN", "F_OBS", "F_REWARD", "F_DONE",
           "F_EE", "F_DONE_BITS", "F_ZMIN", "F_RETURN_RING")
 KNOBS = ("MT_CHAINS", "MT_GRAPH", "MT_TRIG_TABLE", "MT_SPLIT", "MT_PREFETCH", "MT_RESET_SPLIT", "MT_LAZY_CHAINS", "MT_ROLLOUT_K",
-         "MT_ROLLOUT_EARLY", "MT_DEFER_RESET", "MT_ROLLOUT_SNAP")
+         "MT_ROLLOUT_EARLY", "MT_DEFER_RESET", "MT_ROLLOUT_SNAP", "MT_DEFER_RESET_CHAINS")
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--minutes", type=float, default=3.0)
@@ -67,7 +67,8 @@ while time.time() < deadline:
     knobs = {"MT_CHAINS": rng.randint(1, 5), "MT_GRAPH": rng.randint(2), "MT_TRIG_TABLE": rng.randint(2),
              "MT_SPLIT": rng.choice([0, 2, 4]), "MT_PREFETCH": rng.randint(2), "MT_RESET_SPLIT": rng.randint(2),
              "MT_LAZY_CHAINS": int(rng.rand() < 0.8), "MT_ROLLOUT_K": int(rng.choice([1, 1, 2, 3, 4, 5, 5, 9])),
-             "MT_ROLLOUT_EARLY": rng.randint(2), "MT_DEFER_RESET": rng.randint(2), "MT_ROLLOUT_SNAP": rng.randint(2)}
+             "MT_ROLLOUT_EARLY": rng.randint(2), "MT_DEFER_RESET": rng.randint(2), "MT_ROLLOUT_SNAP": rng.randint(2),
+             "MT_DEFER_RESET_CHAINS": rng.randint(2)}
 
     def run(env):
         for key in KNOBS:
@@ -110,7 +111,8 @@ while time.time() < deadline:
         return out, p0, t + 2
 
     plain, p0, total = run({"MT_CHAINS": 1, "MT_GRAPH": 0, "MT_TRIG_TABLE": 0, "MT_SPLIT": 0, "MT_PREFETCH": 0, "MT_RESET_SPLIT": 0,
-                            "MT_LAZY_CHAINS": 0, "MT_ROLLOUT_K": 1, "MT_ROLLOUT_EARLY": 0, "MT_DEFER_RESET": 0, "MT_ROLLOUT_SNAP": 0})
+                            "MT_LAZY_CHAINS": 0, "MT_ROLLOUT_K": 1, "MT_ROLLOUT_EARLY": 0, "MT_DEFER_RESET": 0, "MT_ROLLOUT_SNAP": 0,
+                            "MT_DEFER_RESET_CHAINS": 0})
     got, p1, _ = run(knobs)
     for f in plain:
         assert np.array_equal(plain[f], got[f]), (f, knobs, n, k, dof, substeps, plan, seed)

@@ -253,6 +253,65 @@ def _bench_loop_worker(rank, world, port, steps, warmup, q):
     dist.destroy_process_group()
 
 
+def test_episode_first_launch_stays_outside_the_step_laps():
+    """Where mt_rollout absorbs the episode's reset into its first launch, bench.EpisodeLoop issues that launch (reset
+    prologue + k steps) as a rollout call of its own outside the step laps: the region still runs EXACTLY `steps` steps, the
+    laps hold the other steps only, and the calls are cut where one rollout call would cut its launches."""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    class Rec(_FakeEngine):
+        def __init__(self):
+            self.n_total, self.base, self.n = 64, 0, 64
+            self.ret = torch.zeros(64)
+            self.launches = self.gathers = self.resets = 0
+            self.laps, self.calls = [], []
+
+        def rollout(self, steps, seed, step0):
+            self.calls.append((steps, step0, self.open))
+            super().rollout(steps, seed, step0)
+
+        def gather_returns(self, out=None, field=None, snapshot=True):
+            self.gathers += 1
+            return self.ret.clone()
+
+        gather_begin = gather_returns
+
+        def lap_begin(self, what=None):
+            self.laps.append(what)
+            self.open = True
+
+        def lap_end(self, what=None):
+            self.open = False
+
+    for phase, want_calls in ((0, [(5, 0, False), (15, 5, True)]),
+                              (10, [(10, 10, True), (5, 0, False), (5, 5, True)])):
+        eng = Rec()
+        eng.open = False
+        loop = bench.EpisodeLoop(bench.TimedEngine(eng), 1, 20, steps_per_launch=5, absorbs_reset=True)
+        loop.phase = phase
+        loop.align()
+        eng.calls.clear()
+        before = eng.launches
+        loop.eng.start_region()
+        lapped, gathers = loop.run(20, time_kernels=True)
+        assert eng.launches - before == 20 and gathers == 1
+        assert [(s, s0 % 20, in_lap) for s, s0, in_lap in eng.calls] == want_calls
+        assert lapped == 15 and loop.head_launches == 1 and loop.kernel_launches == 3
+    # a region no longer than the first launch: lapped whole (nothing else to time)
+    eng = Rec()
+    eng.open = False
+    loop = bench.EpisodeLoop(bench.TimedEngine(eng), 1, 5, steps_per_launch=5, absorbs_reset=True)
+    loop.eng.start_region()
+    assert loop.run(5, time_kernels=True) == (5, 1) and loop.head_launches == 0
+    # an engine that does not absorb: one lapped call per segment, as ever
+    eng = Rec()
+    eng.open = False
+    loop = bench.EpisodeLoop(bench.TimedEngine(eng), 1, 20, steps_per_launch=5)
+    loop.eng.start_region()
+    assert loop.run(20, time_kernels=True) == (20, 1) and [c[0] for c in eng.calls] == [20]
+
+
 @pytest.mark.parametrize("steps,warmup", [(20, 5), (1000, 50), (7, 0)])
 def test_bench_episode_loop_world2_gloo(steps, warmup):
     """The driver's invocation `--steps 20 --warmup 5` (and the default, and a tiny one): every timed region launches

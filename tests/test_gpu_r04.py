@@ -201,7 +201,7 @@ def _episode_script(m, e, name, seed, on_torch_stream=False):
         e.sample_actions(seed, 77)
         e.step()
         e.rollout(3, seed, 78)
-    elif name == "one_step_rollouts":                    # mt_rollout(1) cannot absorb the reset
+    elif name == "one_step_rollouts":                    # single-step rollouts: the first one absorbs the reset
         e.rollout(5, seed, 0)
         e.reset_random(seed, 1)
         e.rollout(1, seed, 5)
@@ -230,6 +230,17 @@ def _episode_script(m, e, name, seed, on_torch_stream=False):
         e.reset_random(seed, 2)
         e.reset_done(seed)
         e.rollout(5, seed, 11)
+    elif name == "timers_and_single_step":               # timers do not launch a deferred reset; a one-step rollout absorbs it
+        e.rollout(6, seed, 0)
+        e.reset_random(seed, 1)
+        e.timer_start()
+        e.rollout(1, seed, 6)
+        assert e.timer_stop() > 0.0
+        e.reset_random(seed, 2)
+        e.lap_begin()                                    # (a lap starts behind everything before it: launches the reset)
+        e.rollout(3, seed, 7)
+        e.lap_end()
+        assert len(e.lap_times()) == 1
     else:
         raise AssertionError(name)
     torch.cuda.synchronize()
@@ -238,7 +249,7 @@ def _episode_script(m, e, name, seed, on_torch_stream=False):
 
 
 @pytest.mark.parametrize("script", ["loop", "read_after_reset", "reset_twice", "staged_step", "one_step_rollouts", "inplace_gather",
-                                    "device_view", "fused_and_done"])
+                                    "device_view", "fused_and_done", "timers_and_single_step"])
 @pytest.mark.parametrize("on_torch_stream", [False, True])
 @pytest.mark.parametrize("n,k,table_name,chains", [(131072, 7, "ref", None), (3001, 9, "ref", None), (200003, 7, "ref", None),
                                                    (70001, 3, "dh7", None), (9001, 5, "rt5", None), (100003, 7, "ref", "2")])
@@ -282,7 +293,7 @@ def test_reset_and_snapshot_folded_into_rollout_launches_equal_the_eager_forms(m
 
 
 @pytest.mark.parametrize("script", ["loop", "read_after_reset", "reset_twice", "staged_step", "one_step_rollouts", "inplace_gather",
-                                    "device_view", "fused_and_done"])
+                                    "device_view", "fused_and_done", "timers_and_single_step"])
 @pytest.mark.parametrize("n,k,table_name,env", [(300007, 7, "ref", {}), (530000, 5, "dh7", {}),
                                                 (70001, 3, "ref", {"MT_CHAINS": "3", "MT_ROLLOUT_K": "1", "MT_GRAPH": "0"})])
 def test_reset_folded_into_the_first_launch_of_each_chain_equals_the_eager_form(m, monkeypatch, n, k, table_name, env, script):
