@@ -171,8 +171,10 @@ MT_API int mt_reset(mt_handle h, const float* points, int layout, int is_device)
 /* On a handle that runs on its OWN stream and whose mt_rollout runs several steps per launch (<= 262 144 envs), the launch of
  * mt_reset_random is deferred: the next mt_rollout performs the reset as the prologue of its first launch (the same state,
  * bit for bit, one launch and one round trip of the state less), and every other entry point -- mt_sync included, which is
- * what the own-stream contract asks for before anything else looks at the state -- launches it first.  On a caller's stream
- * (mt_set_stream) the reset is launched by the call itself, in stream order.  MT_DEFER_RESET=0 disables the deferral. */
+ * what the own-stream contract asks for before anything else looks at the state -- launches it first; only the region
+ * timers (mt_timer_start / mt_timer_stop*) leave it alone, it belongs to what follows them.  A single-step mt_rollout absorbs it
+ * as well.  On a caller's stream (mt_set_stream) the reset is launched by the call itself, in stream order.
+ * MT_DEFER_RESET=0 disables the deferral. */
 MT_API int mt_reset_random(mt_handle h, uint64_t seed, uint32_t episode);
 /* Re-arm only the envs whose done byte is 1: their return goes to MT_F_LAST_RETURN and into MT_F_RETURN_RING, their
  * episode index (MT_F_EPISODES) advances by one and keys the new targets (device RNG), pose and return are zeroed.
@@ -308,7 +310,8 @@ typedef struct mt_return_stats {
 } mt_return_stats;
 MT_API int mt_reduce_returns(mt_handle h, int field, int row, mt_return_stats* out);
 
-/* HIP-event timer on the handle's stream (wall-clock of test_multi.py:16-18, device side). */
+/* HIP-event timer on the handle's stream (wall-clock of test_multi.py:16-18, device side).  Start and stop join the chains
+ * but do not launch a deferred mt_reset_random: the next mt_rollout absorbs it INSIDE the timed region. */
 MT_API int mt_timer_start(mt_handle h);
 MT_API int mt_timer_stop(mt_handle h, float* elapsed_ms);
 /* The same end mark WITHOUT joining the chains and without a host wait: one end event on every stream of the handle
@@ -320,7 +323,9 @@ MT_API int mt_timer_stop_async(mt_handle h);
 MT_API int mt_timer_read(mt_handle h, float* elapsed_ms);
 /* Lap timer: any number of begin/end event pairs recorded on the stream WITHOUT host synchronisation;
  * mt_timer_laps_total synchronises once, returns the summed device time of all laps and clears them.  Lets a
- * benchmark time only its step launches inside a longer region without stalling the GPU at every lap. */
+ * benchmark time only its step launches inside a longer region without stalling the GPU at every lap.  A lap begins behind
+ * everything queued before it (a deferred reset is launched first); while the chains are forked on the handle's own stream it
+ * has one begin event per chain and runs from the earliest of them to the latest end event -- no join for the stopwatch. */
 MT_API int mt_timer_lap_begin(mt_handle h);
 MT_API int mt_timer_lap_end(mt_handle h);
 MT_API int mt_timer_laps_total(mt_handle h, float* total_ms, int* n_laps);
