@@ -1624,12 +1624,12 @@ int mt_rollout(mt_handle h, int n_steps, uint64_t seed, uint32_t step_idx0) {
           h->stream = c == 0 ? root : h->chain_streams[c];
           RolloutArgs r = args_of(s0);
           if (r.snap) r.snap += off;
-          if (fresh && s0 == 0 && c > 0) (void)order_behind_inplace_gather(h, h->stream);
-          launch_rollout(h, args_for_range(h, a, off, std::min(span, h->n - off)), h->chain_rollout_split, r, h->rollout_early);
+          if (fresh && s0 == 0 && c > 0 && rc == MT_OK) rc = order_behind_inplace_gather(h, h->stream);
+          if (rc == MT_OK) launch_rollout(h, args_for_range(h, a, off, std::min(span, h->n - off)), h->chain_rollout_split, r, h->rollout_early);
         }
       }
       h->stream = root;
-      rc = check_launch(h, "rollout_kernel (mt_rollout, per chain)");
+      if (rc == MT_OK) rc = check_launch(h, "rollout_kernel (mt_rollout, per chain)");
       if (rc) return rc;
       rc = settle_chains(h);
     } else {
@@ -1698,15 +1698,15 @@ int mt_rollout(mt_handle h, int n_steps, uint64_t seed, uint32_t step_idx0) {
         if (chained_fresh && st == 0 && off < h->n) {
           // the episode's first step: ONE step of the rollout kernel with the deferred reset as its prologue (the state of
           // reset_kernel + step_kernel, bit for bit: no reset launch, no re-fetch of what it would have written)
-          (void)order_behind_inplace_gather(h, h->stream);  // (the in-kernel reset writes MT_F_LAST_RETURN)
+          if (rc == MT_OK) rc = order_behind_inplace_gather(h, h->stream);  // (the in-kernel reset writes MT_F_LAST_RETURN)
           const RolloutArgs r{1, step_idx0, 0u, h->cfg.radius, 1u, h->pend_episode, (uint32_t)h->pend_seed, (uint32_t)(h->pend_seed >> 32), nullptr};
-          launch_rollout(h, args_for_range(h, a, off, std::min(span, h->n - off)), 1, r, h->rollout_early);
+          if (rc == MT_OK) launch_rollout(h, args_for_range(h, a, off, std::min(span, h->n - off)), 1, r, h->rollout_early);
           continue;
         }
-        launch_chain(h, a, step_idx0 + (uint32_t)st, 1, chains, c);
+        if (rc == MT_OK) launch_chain(h, a, step_idx0 + (uint32_t)st, 1, chains, c);
       }
     h->stream = root;
-    rc = check_launch(h, "step_kernel (chained)");
+    if (rc == MT_OK) rc = check_launch(h, "step_kernel (chained)");
     if (rc) return rc;
     rc = settle_chains(h);
     if (rc) return rc;

@@ -9,9 +9,13 @@
 //   writevalue : hipStreamWriteValue32(main, sig, epoch) + hipStreamWaitValue32(side, sig, epoch, GTE)   (signal memory)
 //   kernelflag : the short kernel's LAST block stores epoch to sig itself; the side stream waits with hipStreamWaitValue32
 //                -- nothing extra is queued on the main stream
+//   stopevent  : the short kernel is launched with hipExtLaunchKernelGGL(..., stopEvent = ev): the event IS the kernel's own
+//                completion signal, no barrier packet behind it; the side stream waits for that event
+//   stopevent_nofence : the same with an event created with hipEventDisableSystemFence | hipEventDisableTiming
 // Printed: us per iteration on the main stream's timeline (events around 200 back-to-back iterations) and the side kernels' count.
 // Build: hipcc -O3 --offload-arch=gfx950 tools/microbench/cross_stream.hip -o tools/microbench/cross_stream
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cstdio>
 #include <cstdlib>
@@ -85,14 +89,16 @@ int main() {
   CK(hipEventCreate(&t1));
   const dim3 g(n / 256), blk(256);
   unsigned epoch = 0;
-  const char* names[] = {"none", "event", "event_nofence", "writevalue", "kernelflag"};
-  for (int mode = 0; mode < 5; ++mode) {
-    if (mode >= 3 && !can) continue;
+  const char* names[] = {"none", "event", "event_nofence", "writevalue", "kernelflag", "stopevent", "stopevent_nofence"};
+  for (int mode = 0; mode < 7; ++mode) {
+    if ((mode == 3 || mode == 4) && !can) continue;
     auto iteration = [&]() -> hipError_t {
       hipLaunchKernelGGL(k_long, g, blk, 0, mainS, a, n, iters_long);
       ++epoch;
       if (mode == 4)
         hipLaunchKernelGGL(k_copy_flag, g, blk, 0, mainS, b, a, n, counter, sig, epoch);
+      else if (mode >= 5)
+        hipExtLaunchKernelGGL(k_copy, g, blk, 0, mainS, nullptr, mode == 5 ? ev : ev_nf, 0, b, (const float*)a, n);
       else
         hipLaunchKernelGGL(k_copy, g, blk, 0, mainS, b, a, n);
       hipError_t e = hipSuccess;
@@ -107,6 +113,8 @@ int main() {
         if (e == hipSuccess) e = hipStreamWaitValue32(side, sig, epoch, hipStreamWaitValueGte, 0xFFFFFFFFu);
       } else if (mode == 4) {
         e = hipStreamWaitValue32(side, sig, epoch, hipStreamWaitValueGte, 0xFFFFFFFFu);
+      } else if (mode >= 5) {
+        e = hipStreamWaitEvent(side, mode == 5 ? ev : ev_nf, 0);
       }
       if (e != hipSuccess) return e;
       if (mode != 0) hipLaunchKernelGGL(k_copy, g, blk, 0, side, c, b, n);   // the "exchange"
