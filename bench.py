@@ -33,7 +33,9 @@ the engine's streams (mt_timer_start / mt_timer_stop_async: from the idle device
 kernel, reset or exchange, no host wait in between): `value_device_timeline` is the same throughput on that clock, i.e. without
 the host latency of the two fences, which at 8 GPUs x 131 072 arms is a third of a 20-step region.  The device time of a STEP
 is measured with HIP-event laps around the step launches only (mt_rollout may run a step as two concurrent launches on two
-streams that stay forked across calls; a lap ends when the last of them does; `roofline` says so).
+streams that stay forked across calls; a lap begins with the first of them and ends when the last of them does; `roofline`
+says so).  Where mt_rollout takes the episode's reset into its first launch (small shards), that launch -- another kernel --
+is issued as a rollout call of its own outside the laps, inside the region and its device timeline (EpisodeLoop.head_steps).
 
 Prints ONE JSON line on rank 0 (contract: see the task brief / DESIGN.md section "Measurement").
 """

@@ -24,7 +24,8 @@ struct mt_engine {
   hipEvent_t ev1c[kMaxChains] = {nullptr, nullptr, nullptr, nullptr};  // [0] unused (= ev1)
   int timer_ends = 0;              // end events recorded by the last mt_timer_stop_async: ev1 + ev1c[1 .. timer_ends-1]
   bool timer_with_gather = false;  // ... and an exchange was pending then (its end = ev_g1)
-  // mt_timer_lap_*: a lap = one begin event on the handle's stream + one end event per stream that carried work of the lap
+  // mt_timer_lap_*: a lap = one begin event per stream that carries work when it begins (the handle's stream; every chain's
+  // while the chains are forked on the own stream) + one end event per stream that carried work of the lap
   // (the handle's stream, and the chain streams while mt_rollout's chains are forked); its time = begin -> the latest end
   struct LapRec {
     uint32_t begin, n_begin, end0, n_end;  // indices into lap_events: begin .. begin + n_begin - 1, end0 .. end0 + n_end - 1
