@@ -71,6 +71,45 @@ __device__ __forceinline__ uint32_t lane_offset(LaneOffset<RENEW>& o) {
 #endif
   return o.v;
 }
+// MT_BUFFER_ROWS: the same access as a BUFFER instruction -- `buffer_load/store v, v_off, s[rsrc:rsrc+3], 0 offen`: the row
+// base sits in a 128-bit resource descriptor in SGPRs (built by the scalar unit: base, no stride, no range check, the raw
+// 32-bit data format of gfx94x / gfx950), the lane's byte offset is the VGPR operand by construction.  Neither the 64-bit
+// per-lane adds of the plain form nor the renewal asm of the saddr form (a scheduling barrier at every access) are needed.
+#ifndef MT_BUFFER_ROWS
+#define MT_BUFFER_ROWS 0
+#endif
+#if MT_BUFFER_ROWS
+constexpr int kRsrcWord3 = 0x00020000;  // raw buffer, DATA_FORMAT = 32 (gfx90a / gfx94x / gfx950)
+constexpr int kAuxNt = 2;               // cache policy: non-temporal (the `nt` bit of gfx94x)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t row_rsrc(const void* row) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)uniform_row(row), 0, -1, kRsrcWord3);  // num_records = 2^32 - 1: no clamp
+}
+template <typename T, bool R>
+__device__ __forceinline__ T ldr(const T* row, LaneOffset<R>& o) {
+  static_assert(sizeof(T) == 4 || sizeof(T) == 1, "rows hold 32-bit words or bytes");
+  if constexpr (sizeof(T) == 4)
+    return __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b32(row_rsrc(row), (int)o.v, 0, 0));
+  else
+    return __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b8(row_rsrc(row), (int)o.v, 0, 0));
+}
+template <typename T, bool R>
+__device__ __forceinline__ void str(T* row, LaneOffset<R>& o, T v) {
+  static_assert(sizeof(T) == 4 || sizeof(T) == 1, "rows hold 32-bit words or bytes");
+  if constexpr (sizeof(T) == 4)
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), row_rsrc(row), (int)o.v, 0, 0);
+  else
+    __builtin_amdgcn_raw_buffer_store_b8(__builtin_bit_cast(uint8_t, v), row_rsrc(row), (int)o.v, 0, 0);
+}
+template <typename T, bool R>
+__device__ __forceinline__ void str_stream(T* row, LaneOffset<R>& o, T v) {
+  static_assert(sizeof(T) == 4 || sizeof(T) == 1, "rows hold 32-bit words or bytes");
+  constexpr int aux = MT_NT_STORES ? kAuxNt : 0;
+  if constexpr (sizeof(T) == 4)
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), row_rsrc(row), (int)o.v, 0, aux);
+  else
+    __builtin_amdgcn_raw_buffer_store_b8(__builtin_bit_cast(uint8_t, v), row_rsrc(row), (int)o.v, 0, aux);
+}
+#else
 template <typename T, bool R>
 __device__ __forceinline__ T ldr(const T* row, LaneOffset<R>& o) {
   return *(global_ptr<const T>)(uniform_row(row) + lane_offset(o));
@@ -88,6 +127,7 @@ __device__ __forceinline__ void str_stream(T* row, LaneOffset<R>& o, T v) {
   *p = v;
 #endif
 }
+#endif
 
 // ---------------------------------------------------------------------------
 // DH table views.  The chain code below is written once against this
