@@ -288,7 +288,13 @@ MT_API int mt_gather_returns(mt_handle h, int field, int row, float* dst, int64_
  * behind the last begun gather; with host_wait != 0 it also blocks the calling thread until dst is complete and, if
  * elapsed_ms is not NULL, reports the device time the exchange took (if mt_sync has already waited for it: the time
  * of that last completed exchange).  dst must not be read, and the communicator not destroyed, before that.  mt_sync
- * also waits for a begun gather. */
+ * also waits for a begun gather.
+ * Several gathers may be begun without a wait in between (each with a dst of its own): they run one after the other on the
+ * side stream.  The snapshot is double-buffered, and where mt_rollout writes it itself (its last launch, small batches)
+ * mt_gather_returns_begin lets the calling thread run at most ONE exchange ahead of the device: if the exchange before the one
+ * just begun has not finished yet it waits for it (the device still holds a whole episode of queued work then), so that the
+ * next episode needs neither a snapshot launch nor a stream wait between its steps and the gather.  MT_GATHER_THROTTLE=0
+ * never waits (the snapshot is then a launch of its own whenever the host is further ahead). */
 MT_API int mt_gather_returns_begin(mt_handle h, int field, int row, float* dst, int64_t dst_elems);
 MT_API int mt_gather_returns_wait(mt_handle h, int host_wait, float* elapsed_ms);
 /* The same without the snapshot: the exchange on the side stream reads the arena row itself, so nothing is copied on the

@@ -111,6 +111,13 @@ void mt_gather_release(mt_handle h) {
   if (h->ev_snap) (void)hipEventDestroy(h->ev_snap);
   if (h->ev_g0) (void)hipEventDestroy(h->ev_g0);
   if (h->ev_g1) (void)hipEventDestroy(h->ev_g1);
+  for (int p = 0; p < 2; ++p) {
+    if (h->ev_gdone[p]) (void)hipEventDestroy(h->ev_gdone[p]);
+    h->ev_gdone[p] = nullptr;
+    h->snap_free_known[p] = true;
+  }
+  h->snap_next = 0;
+  h->snap_valid = false;
   if (h->snap) (void)hipFree(h->snap);
   if (h->reduce_scratch) (void)hipFree(h->reduce_scratch);
   h->reduce_scratch = nullptr;
@@ -451,7 +458,8 @@ static int gather_begin_impl(mt_handle h, int field, int row, float* dst, int64_
     if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_snap, mt::event_flags(false));
     if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_g0, mt::event_flags(true));
     if (e == hipSuccess) e = hipEventCreate(&h->ev_g1);  // (default: mt_gather_returns_wait(host) hands dst to the caller behind it)
-    if (e == hipSuccess) e = hipMalloc(&h->snap, sizeof(float) * (size_t)h->n);
+    for (int p = 0; p < 2 && e == hipSuccess; ++p) e = hipEventCreateWithFlags(&h->ev_gdone[p], mt::event_flags(false));
+    if (e == hipSuccess) e = hipMalloc(&h->snap, sizeof(float) * 2 * (size_t)h->n);  // two rows: see engine_internal.h
     if (e != hipSuccess) {
       (void)hipGetLastError();
       mt_gather_release(h);  // whatever was created goes again: the next call starts from scratch
@@ -459,22 +467,37 @@ static int gather_begin_impl(mt_handle h, int field, int row, float* dst, int64_
                   std::string("mt_gather_returns_begin: set-up of the side stream failed: ") + hipGetErrorString(e));
     }
   }
-  // the snapshot (and the communicator's staging) may only be reused once the previous exchange has finished
-  rc = order_behind_pending_gather(h, h->stream);
-  if (rc) return rc;
+  // Exchanges run one after the other on the side stream (one communicator, one staging buffer): nothing on the handle's
+  // stream has to wait for the previous one -- unless it reads an arena row in place (the writers of that row are ordered
+  // behind `the pending in-place exchange`, of which there is one) -- and the snapshot row of THIS exchange is free once the
+  // exchange before the previous one, which read it, has finished.
+  if (h->gather_pending && h->gather_inplace) {
+    rc = order_behind_pending_gather(h, h->stream);
+    if (rc) return rc;
+  }
+  const int p = h->snap_next;
+  float* const snap = h->snap_row(p);
+  auto row_is_free = [&](hipStream_t s) -> int {  // before a copy into the row on stream `s`
+    if (!h->snap_free_known[p]) {
+      if (hipEventQuery(h->ev_gdone[p]) == hipSuccess) {
+        h->snap_free_known[p] = true;
+      } else {
+        (void)hipGetLastError();
+        MT_HIP(h, hipStreamWaitEvent(s, h->ev_gdone[p], 0));
+      }
+    }
+    return MT_OK;
+  };
   if (per_chain) {
     const int64_t per = (h->n + h->chains - 1) / h->chains, span = (per + 255) / 256 * 256;  // engine.hip: chain_span
     for (int c = 0; c < h->chains; ++c) {
       const int64_t off = (int64_t)c * span;
       if (off >= h->n) continue;
       hipStream_t sc = c == 0 ? h->stream : h->chain_streams[c];
-      if (c > 0) {
-        rc = order_behind_pending_gather(h, sc);
-        if (rc) return rc;
-      }
       const int64_t cnt = std::min(span, h->n - off);
       if (!have_snap) {
-        rc = row_copy(h, h->snap + off, src + off, cnt, sc);
+        rc = row_is_free(sc);
+        if (rc == MT_OK) rc = row_copy(h, snap + off, src + off, cnt, sc);
         if (rc) return rc;
       }
       if (c > 0) {
@@ -484,13 +507,14 @@ static int gather_begin_impl(mt_handle h, int field, int row, float* dst, int64_
         MT_HIP(h, hipStreamWaitEvent(h->side_stream, h->ev_join[c], 0));
       }
     }
-    src = h->snap;
+    src = snap;
   } else if (!inplace) {
     if (!have_snap) {
-      rc = row_copy(h, h->snap, src, h->n, h->stream);
+      rc = row_is_free(h->stream);
+      if (rc == MT_OK) rc = row_copy(h, snap, src, h->n, h->stream);
       if (rc) return rc;
     }
-    src = h->snap;
+    src = snap;
   }
   MT_HIP(h, hipEventRecord(h->ev_snap, h->stream));
   MT_HIP(h, hipStreamWaitEvent(h->side_stream, h->ev_snap, 0));
@@ -500,6 +524,31 @@ static int gather_begin_impl(mt_handle h, int field, int row, float* dst, int64_
   MT_HIP(h, hipEventRecord(h->ev_g1, h->side_stream));
   h->gather_pending = true;
   h->gather_inplace = inplace;
+  if (!inplace) {
+    MT_HIP(h, hipEventRecord(h->ev_gdone[p], h->side_stream));
+    h->snap_free_known[p] = false;
+    h->snap_next = p ^ 1;
+    // The row the next mt_rollout's last launch will write was read by the exchange BEFORE this one: let the host learn
+    // that it has finished -- by waiting for it if the host has run that far ahead of the device (an unfenced episode loop
+    // enqueues an episode in a third of the time the device needs for it).  The device is not idle meanwhile: it still has
+    // the whole episode that ends in this exchange in its queue.  Without this a snapshot launch of its own and a stream
+    // wait sit between the episodes (21 us of a 130 us episode at 131 072 envs: tools/shard_timeline.py).
+    const int q = h->snap_next;
+    if (!h->snap_free_known[q] && h->gather_throttle && h->snap_in_rollout && h->stream == h->own_stream) {
+      for (int spins = 0;; ++spins) {
+        const hipError_t e = hipEventQuery(h->ev_gdone[q]);
+        if (e == hipSuccess) break;
+        (void)hipGetLastError();
+        if (e != hipErrorNotReady) return fail(h, MT_ERR_HIP, std::string("hipEventQuery: ") + hipGetErrorString(e));
+        if (spins > 20000) {  // (a long exchange: sleep instead of spinning on)
+          MT_HIP(h, hipEventSynchronize(h->ev_gdone[q]));
+          break;
+        }
+        __builtin_ia32_pause();
+      }
+      h->snap_free_known[q] = true;
+    }
+  }
   return MT_OK;
 }
 
@@ -525,6 +574,7 @@ int mt_gather_returns_wait(mt_handle h, int host_wait, float* elapsed_ms) {
     MT_HIP(h, hipEventElapsedTime(&h->last_gather_ms, h->ev_g0, h->ev_g1));
     if (elapsed_ms) *elapsed_ms = h->last_gather_ms;
     h->gather_pending = false;
+    h->snap_free_known[0] = h->snap_free_known[1] = true;  // the latest exchange has finished, and so have the ones before it
   }
   return MT_OK;
 }

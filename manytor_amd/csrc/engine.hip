@@ -311,6 +311,11 @@ static void choose_dispatch(mt_handle h) {
     h->defer_reset_chained = v != 0;
     seen("MT_DEFER_RESET_CHAINS");
   }
+  h->gather_throttle = true;
+  if (env_int("MT_GATHER_THROTTLE", &v)) {  // 0: mt_gather_returns_begin never waits on the host (a snapshot launch instead)
+    h->gather_throttle = v != 0;
+    seen("MT_GATHER_THROTTLE");
+  }
   h->snap_in_rollout = true;
   if (env_int("MT_ROLLOUT_SNAP", &v)) {
     h->snap_in_rollout = v != 0;
@@ -1063,6 +1068,7 @@ int mt_sync(mt_handle h) {
     MT_HIP(h, hipStreamSynchronize(h->side_stream));
     MT_HIP(h, hipEventElapsedTime(&h->last_gather_ms, h->ev_g0, h->ev_g1));
     h->gather_pending = false;
+    h->snap_free_known[0] = h->snap_free_known[1] = true;  // every exchange has finished
   }
   return MT_OK;
 }
@@ -1587,11 +1593,14 @@ int mt_rollout(mt_handle h, int n_steps, uint64_t seed, uint32_t step_idx0) {
     a.seed_hi = (uint32_t)(seed >> 32);
     const bool fresh = h->reset_pending;
     h->reset_pending = false;
-    // the snapshot row may be written only while no exchange is still reading it (the previous one has finished long ago
-    // in an episode loop: asked, not waited for) and only on the handle's stream proper
+    // the snapshot row of the next exchange (double-buffered: engine_internal.h) may be written once the exchange that last
+    // read it is known to have finished: asked, never waited for (mt_gather_returns_begin keeps the host informed)
     bool snap = h->snap_in_rollout && h->snap != nullptr;
-    if (snap && h->gather_pending) {
-      if (hipEventQuery(h->ev_g1) != hipSuccess) {
+    const int snap_p = h->snap_next;
+    if (snap && !h->snap_free_known[snap_p]) {
+      if (hipEventQuery(h->ev_gdone[snap_p]) == hipSuccess) {
+        h->snap_free_known[snap_p] = true;
+      } else {
         (void)hipGetLastError();
         snap = false;
       }
@@ -1604,7 +1613,7 @@ int mt_rollout(mt_handle h, int n_steps, uint64_t seed, uint32_t step_idx0) {
         r.reset_seed_lo = (uint32_t)h->pend_seed;
         r.reset_seed_hi = (uint32_t)(h->pend_seed >> 32);
       }
-      if (snap && s0 + h->multi_k >= n_steps) r.snap = h->snap;
+      if (snap && s0 + h->multi_k >= n_steps) r.snap = h->snap_row(snap_p);
       return r;
     };
     int rc = MT_OK;

@@ -61,7 +61,17 @@ struct mt_engine {
   // mt_gather_returns_begin / _wait: the exchange runs on a side stream from a snapshot of the row
   hipStream_t side_stream = nullptr;
   hipEvent_t ev_snap = nullptr, ev_g0 = nullptr, ev_g1 = nullptr;
+  // The overlapped gather's snapshot is double-buffered: rows 0 / 1 of `snap` ([2][n]) alternate from exchange to exchange, so
+  // that the row the NEXT mt_rollout's last launch writes (snap_next) is not the one the exchange still in flight reads.  A
+  // row may be written once the exchange that last read it is KNOWN on the host to have finished (snap_free_known; asked with
+  // hipEventQuery on ev_gdone[row], never waited for on the device); mt_gather_returns_begin keeps that true by letting the
+  // host run at most one exchange ahead of the device (gather_throttle).
   float* snap = nullptr;
+  hipEvent_t ev_gdone[2] = {nullptr, nullptr};
+  bool snap_free_known[2] = {true, true};
+  int snap_next = 0;
+  bool gather_throttle = true;
+  float* snap_row(int p) const { return snap + (size_t)p * (size_t)n; }
   void* reduce_scratch = nullptr;  // mt_reduce_returns: block partials + per-rank records, grown on demand
   size_t reduce_scratch_bytes = 0;
   bool reset_split = false;  // mt_reset_random / mt_reset_done of the whole batch: reset_split_kernel
