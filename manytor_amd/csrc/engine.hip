@@ -556,6 +556,7 @@ StepArgs args_for_env(mt_handle h, int64_t env) {
   a.last_return += env;
   if (a.ring) a.ring += env;
   if (a.zmin) a.zmin += env;
+  a.snap = nullptr;
   a.n = 1;
   a.env_base += env;
   return a;
@@ -579,6 +580,7 @@ StepArgs args_for_range(mt_handle h, const StepArgs& base, int64_t off, int64_t 
   a.last_return += off;
   if (a.ring) a.ring += off;
   if (a.zmin) a.zmin += off;
+  if (a.snap) a.snap += off;
   a.n = cnt;
   a.env_base += off;
   return a;
@@ -919,6 +921,7 @@ int mt_create(mt_handle* out, const mt_config* cfg) {
   h->spare_bits = (unsigned long long*)(base + o_misc + 64);  // ballot sink of single-env launches
   h->trace = (cfg->flags & MT_FLAG_TRACE) ? (float*)(base + o_trace) : nullptr;
   a.zmin = (cfg->flags & MT_FLAG_DEBUG_ZMIN) ? (float*)(base + o_zmin) : nullptr;
+  a.snap = nullptr;  // set on copies of the arguments only: the last step launch of an mt_rollout (chained form)
   a.trig_table = (const float*)(base + o_trig);
   hipLaunchKernelGGL(fill_trig_table_kernel, dim3(1), dim3(kBlock), 0, h->stream, (float*)(base + o_trig));
   MT_HIP_C(hipGetLastError());
@@ -1027,7 +1030,7 @@ const char* mt_describe_dispatch(mt_handle h) {
       "\",\"steps_per_launch\":" + num(multi ? h->multi_k : 1) + ",\"graph\":" + b(!multi && graph) +
       ",\"lanes_per_env\":" + num(std::max(1, multi ? ((h->chains > 1 && h->chains_forced) ? h->chain_rollout_split : h->rollout_split) : (rec ? (h->chains > 1 ? h->chain_split : h->split) : 0))) +
       ",\"chains\":" + num(multi && !h->chains_forced ? 1 : h->chains) +
-      ",\"absorbs_reset\":" + b(h->defer_reset && (multi || chained_rollout_absorbs_reset(h))) + ",\"writes_snapshot\":" + b(multi && h->snap_in_rollout) + "}" +
+      ",\"absorbs_reset\":" + b(h->defer_reset && (multi || chained_rollout_absorbs_reset(h))) + ",\"writes_snapshot\":" + b(h->snap_in_rollout && (multi || (h->chains > 1 && !graph && !h->trace))) + "}" +
       ",\"fused\":{\"usable\":" + b(fusable(h)) + ",\"lanes_per_env\":" + num(h->rollout_split ? h->rollout_split : 1) + "}" +
       ",\"reset\":{\"lanes_per_env\":" + num(h->reset_split ? 4 : 1) + "}" +
       ",\"overrides\":\"" + h->overrides + "\"" +
@@ -1700,6 +1703,22 @@ int mt_rollout(mt_handle h, int n_steps, uint64_t seed, uint32_t step_idx0) {
     hipStream_t root = h->stream;
     const int64_t span = chain_span(h, chains);
     h->reset_pending = false;
+    // the last step launch of every chain also stores its returns to the overlapped gather's next snapshot row (double-
+    // buffered: engine_internal.h), once the exchange that last read that row is known to have finished
+    StepArgs a_last = a;
+    {
+      const int sp = h->snap_next;
+      bool snap = h->snap_in_rollout && h->snap != nullptr && !h->trace;
+      if (snap && !h->snap_free_known[sp]) {
+        if (hipEventQuery(h->ev_gdone[sp]) == hipSuccess) {
+          h->snap_free_known[sp] = true;
+        } else {
+          (void)hipGetLastError();
+          snap = false;
+        }
+      }
+      if (snap) a_last.snap = h->snap_row(sp);
+    }
     for (int st = 0; st < n_steps; ++st)
       for (int c = 0; c < chains; ++c) {
         h->stream = c == 0 ? root : h->chain_streams[c];
@@ -1712,13 +1731,14 @@ int mt_rollout(mt_handle h, int n_steps, uint64_t seed, uint32_t step_idx0) {
           if (rc == MT_OK) launch_rollout(h, args_for_range(h, a, off, std::min(span, h->n - off)), 1, r, h->rollout_early);
           continue;
         }
-        if (rc == MT_OK) launch_chain(h, a, step_idx0 + (uint32_t)st, 1, chains, c);
+        if (rc == MT_OK) launch_chain(h, st == n_steps - 1 ? a_last : a, step_idx0 + (uint32_t)st, 1, chains, c);
       }
     h->stream = root;
     if (rc == MT_OK) rc = check_launch(h, "step_kernel (chained)");
     if (rc) return rc;
     rc = settle_chains(h);
     if (rc) return rc;
+    h->snap_valid = a_last.snap != nullptr && !(chained_fresh && n_steps == 1);
   } else {
     for (int s = 0; s < n_steps; ++s) {
       int rc = mt_step_random(h, seed, step_idx0 + (uint32_t)s);

@@ -888,6 +888,7 @@ __global__ __launch_bounds__(kBlock, (PF ? 1 : step_min_waves<Tbl, TRIG>())) voi
   str(a.alive, o4, nam);
   str_stream(a.reward, o4, rew);
   str(a.total_reward, o4, total_in + (float)rew);  // manytor.py:258
+  if (a.snap) str(a.snap, o4, total_in + (float)rew);  // (wave-uniform branch on an SGPR pointer, like a.zmin)
   str_stream(a.done, o1, (uint8_t)(done ? 1 : 0));
   const unsigned long long bits = __ballot(done);
   if ((threadIdx.x & 63) == 0) a.done_bits[i >> 6] = bits;
@@ -1110,6 +1111,7 @@ __global__ __launch_bounds__(kBlock) void step_split_kernel(const StepArgs a) {
     a.alive[i] = nam;
     __builtin_nontemporal_store(rew, a.reward + i);
     a.total_reward[i] = total_in + (float)rew;  // manytor.py:258
+    if (a.snap) a.snap[i] = total_in + (float)rew;
     __builtin_nontemporal_store((uint8_t)(done ? 1 : 0), a.done + i);
   }
   // sub-lane 0 occupies lanes 0 .. EPW-1: the low EPW bits of the ballot are this wave's slice of the done_bits word

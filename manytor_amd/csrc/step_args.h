@@ -43,6 +43,7 @@ struct StepArgs {
   uint32_t* bad_actions;          // [1] number of (env, step) pairs whose staged action was not a usable angle
   const float* trig_table;        // [450][2] (sin, cos) of the whole degrees -270 .. 179, filled once at mt_create (kernels.h: SinCos)
   float* zmin;                    // [ld] MT_FLAG_DEBUG_ZMIN only (else NULL): the z-minimum the ground test of the last step used
+  float* snap;                    // [n] NULL, or (the last step launch of an mt_rollout) the overlapped gather's snapshot row: the returns again
   uint32_t ring_slots, episode0;  // episode0 = episode index every env got at the last full reset
   int64_t n, ld, env_base;
   int32_t K, S;

@@ -129,6 +129,7 @@ def test_rollout_default_dispatch_by_size(m, monkeypatch):
         multi = n <= P["multi_step_max"]
         assert d["rollout"]["form"] == ("multi_step" if multi else "chained_steps" if two else "launch_per_step")
         assert d["rollout"]["steps_per_launch"] == (P["multi_step_k"] if multi else 1)
+        assert d["rollout"]["absorbs_reset"] is multi and d["rollout"]["writes_snapshot"] is (multi or two)
         assert d["fused"]["usable"] is True
         assert d["fused"]["lanes_per_env"] == (4 if n <= P["fused_split4_max"] else 2 if n <= P["fused_split2_max"] else 1)
         assert d["reset"]["lanes_per_env"] == (4 if n <= P["reset_split_max"] else 1)
@@ -297,22 +298,26 @@ def test_reset_and_snapshot_folded_into_rollout_launches_equal_the_eager_forms(m
 @pytest.mark.parametrize("n,k,table_name,env", [(300007, 7, "ref", {}), (530000, 5, "dh7", {}),
                                                 (70001, 3, "ref", {"MT_CHAINS": "3", "MT_ROLLOUT_K": "1", "MT_GRAPH": "0"})])
 def test_reset_folded_into_the_first_launch_of_each_chain_equals_the_eager_form(m, monkeypatch, n, k, table_name, env, script):
-    """The chained launch-per-step form of the large batches (MT_DEFER_RESET_CHAINS=1): a deferred mt_reset_random becomes the
-    prologue of ONE step of the rollout kernel at the head of each chain's launches -- the same scripts, the same bits as the
-    eager per-chain reset kernels."""
+    """The chained launch-per-step form of the large batches: the last step launch of every chain writes the overlapped
+    gather's snapshot (default), and with MT_DEFER_RESET_CHAINS=1 a deferred mt_reset_random becomes the prologue of ONE step
+    of the rollout kernel at the head of each chain's launches -- the same scripts, the same bits as the eager per-chain
+    reset kernels and snapshot copies."""
     table, radius = {"ref": (m.REF_DH_TABLE, 51.3), "dh7": (m.DH7_TABLE, 92.6)}[table_name]
     for key, val in env.items():
         monkeypatch.setenv(key, val)
     monkeypatch.setenv("MT_DEFER_RESET", "0")
+    monkeypatch.setenv("MT_ROLLOUT_SNAP", "0")
     ref = m.StepEngine(n, k, dh_table=table, radius=radius, pickup_tol=20.0, return_ring=3)
-    assert ref.dispatch()["rollout"]["absorbs_reset"] is False and ref.dispatch()["rollout"]["form"] == "chained_steps"
+    d = ref.dispatch()["rollout"]
+    assert d["absorbs_reset"] is False and d["writes_snapshot"] is False and d["form"] == "chained_steps"
     want = _episode_script(m, ref, script, 23)
     ref.close()
     monkeypatch.delenv("MT_DEFER_RESET")
+    monkeypatch.delenv("MT_ROLLOUT_SNAP")
     monkeypatch.setenv("MT_DEFER_RESET_CHAINS", "1")
     eng = m.StepEngine(n, k, dh_table=table, radius=radius, pickup_tol=20.0, return_ring=3)
     d = eng.dispatch()["rollout"]
-    assert d["form"] == "chained_steps" and d["graph"] is False and d["absorbs_reset"] is True
+    assert d["form"] == "chained_steps" and d["graph"] is False and d["absorbs_reset"] is True and d["writes_snapshot"] is True
     got = _episode_script(m, eng, script, 23)
     eng.close()
     assert_same(got["final"], want["final"], script)
