@@ -523,6 +523,14 @@ class Fabric:
         return bool(int(t.item()))
 
 
+def fraction_or_none(x):
+    """A fraction of the HBM peak on SURVEY 8(d)'s MODEL bytes (12 D + 24 K + 33 per env-step), or None where the launches
+    move so much less than the model says -- no action read (the action is drawn in registers), the state rows once per k
+    steps -- that model bytes over time would exceed the peak: not a fraction of anything then (the GB/s figure beside it
+    stays; `frac` / `frac_of_hbm_peak` on the bytes really moved is the roofline figure)."""
+    return x if x <= 1.0 else None
+
+
 def rollout_absorbs_reset(raw):
     """Does mt_rollout on this engine take a deferred mt_reset_random into its first launch?  (mt_describe_dispatch)"""
     try:
@@ -976,7 +984,7 @@ def main():
                 "launches_per_step": chains, "envs_per_launch": envs_per_launch,
                 "bytes_per_launch": moved * spl * envs_per_launch, "bytes_per_step": moved * n_local,
                 "bytes_per_env_step_survey_model": bpe, "achieved_survey_model": achieved_model,
-                "frac_survey_model": achieved_model / HBM_PEAK_GBS,
+                "frac_survey_model": fraction_or_none(achieved_model / HBM_PEAK_GBS),
                 "achievable_gbs": ach_hbm,
                 "achievable_note": "mt_stream_probe: the memory operations of one step (same rows read / rewritten / nt-written "
                                    "per env, same addressing, one env per lane) with no arithmetic, over 4 194 304 envs "
@@ -1056,7 +1064,8 @@ def main():
                    "env_steps_per_s": n2 / (us * 1e-6), "steps_per_kernel_launch": spl2,
                    "bytes_per_env_step": b2a, "frac_of_hbm_peak": gbs / HBM_PEAK_GBS,
                    "bytes_per_env_step_survey_model": b2,
-                   "frac_survey_model": b2 * n2 / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, "regime": regime_of(n2, b2a)}
+                   "survey_model_gbs": b2 * n2 / (us * 1e-6) / 1e9,
+                   "frac_survey_model": fraction_or_none(b2 * n2 / (us * 1e-6) / 1e9 / HBM_PEAK_GBS), "regime": regime_of(n2, b2a)}
             if spl2 > 1:    # the pure one-launch-per-step figure beside the k-steps-per-launch default (MT_ROLLOUT_K=1)
                 us1, kname1 = time_step_launches(m, n2, tbl, rad, args.targets, dev, args.seed, steps=600, rollout_k=1)
                 rec["one_launch_per_step"] = {"us_per_step": us1, "kernel": kname1, "env_steps_per_s": n2 / (us1 * 1e-6),

@@ -26,6 +26,10 @@ if roll:
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 28
 j = len(rows) * 3 // 5
 base, prev_end = rows[j][0], rows[j - 1][1]
+last_on_queue = {}
 for r in rows[j:j + count]:
-    print(f"{(r[0] - base) / 1e3:9.1f} {(r[1] - base) / 1e3:9.1f} dur {(r[1] - r[0]) / 1e3:7.1f} gap {(r[0] - prev_end) / 1e3:7.1f} q{r[4]} grid {r[3]:8d} {r[2]}")
+    own = (r[0] - last_on_queue[r[4]]) / 1e3 if r[4] in last_on_queue else float("nan")
+    print(f"{(r[0] - base) / 1e3:9.1f} {(r[1] - base) / 1e3:9.1f} dur {(r[1] - r[0]) / 1e3:7.1f} gap {(r[0] - prev_end) / 1e3:7.1f} "
+          f"(own queue {own:6.1f}) q{r[4]} grid {r[3]:8d} {r[2]}")
     prev_end = max(prev_end, r[1])
+    last_on_queue[r[4]] = r[1]
