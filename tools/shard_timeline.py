@@ -3,7 +3,7 @@
 launch carries the reset as its prologue, the last one writes the gather's snapshot: same kernel name, different durations),
 and the timeline of two regions' worth of kernels from the middle of the run (start / end relative to the first of them, gap
 to the previous kernel on any queue, queue, grid, kernel).
-    python tools/shard_timeline.py <kernel_trace.csv> [rows]"""
+    python tools/shard_timeline.py <kernel_trace.csv> [rows] [position in the run, 0 .. 1, or -N = N rows before the last step launch]"""
 import csv
 import statistics
 import sys
@@ -24,7 +24,12 @@ if roll:
           f"{statistics.mean(plain):.2f}; longer: {len(heavy)} launches, mean {statistics.mean(heavy) if heavy else 0:.2f} "
           f"(the episodes' first launches: reset prologue)")
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 28
-j = len(rows) * 3 // 5
+where = float(sys.argv[3]) if len(sys.argv) > 3 else 0.6   # position in the run: 0.6 = the pre-warm loop (unfenced), 0.9 = timed regions
+if where < 0:     # counted back from the last rollout / step launch of the run: the timed regions
+    last = max(i for i, r in enumerate(rows) if "rollout" in r[2] or "step_kernel" in r[2])
+    j = max(1, last + int(where))
+else:
+    j = int(len(rows) * where)
 base, prev_end = rows[j][0], rows[j - 1][1]
 last_on_queue = {}
 for r in rows[j:j + count]:
