@@ -431,6 +431,35 @@ void launch_step_t(mt_handle h, const StepArgs& args, bool sample, bool whole_ro
 #undef MT_LAUNCH_STEP
 }
 
+// The first step of an episode with the deferred reset as the step kernel's own prologue (kernels.h, FRESH): the sampled-
+// action kernels of the static tables, one env per lane.  false = no such kernel for this handle's schedule (the caller
+// falls back to one step of the rollout kernel).  `args` carries reset_seed / reset_episode / radius.
+template <class Tbl>
+bool launch_step_fresh_t(mt_handle h, const StepArgs& args) {
+  if constexpr (!ActionTrigTable<Tbl>::value) {
+    return false;
+  } else {
+    if (h->trig != 0 || !h->trig_steps || h->split || h->lds_table || h->trace) return false;
+    const size_t stage = (size_t)3 * args.K * kBlock * sizeof(float), fixed = kTrigEntries * sizeof(SinCos) + 512;
+    if (stage + fixed > 65536) return false;  // (K > 20: above the default dynamic-LDS limit)
+    const dim3 g = grid_for(args.n), b(kBlock);
+    const size_t lds = std::max(stage, h->prefetch ? lds_pad_for_blocks(step_blocks_per_cu(h, args.n), fixed) : (size_t)0);
+    if (h->prefetch && args.n >= h->flat_from)
+      hipLaunchKernelGGL((step_kernel<Tbl, true, 0, false, kPrefetch, true, true, true>), g, b, lds, h->stream, args);
+    else if (h->prefetch)
+      hipLaunchKernelGGL((step_kernel<Tbl, true, 0, false, kPrefetch, true, false, true>), g, b, lds, h->stream, args);
+    else
+      hipLaunchKernelGGL((step_kernel<Tbl, true, 0, false, 0, true, false, true>), g, b, lds, h->stream, args);
+    return true;
+  }
+}
+bool launch_step_fresh(mt_handle h, const StepArgs& args) {
+  if (h->custom_frames) return false;
+  if (h->static_kind == 1) return launch_step_fresh_t<Ref4Table>(h, args);
+  if (h->static_kind == 2) return launch_step_fresh_t<Dh7Table>(h, args);
+  return false;
+}
+
 template <int D>
 void launch_step_d(mt_handle h, const StepArgs& args, bool sample, bool whole_rows) {
   launch_step_t<RtTable<D>, true>(h, args, sample, whole_rows);
@@ -516,6 +545,22 @@ void launch_chain(mt_handle h, const StepArgs& a0, uint32_t major0, int T, int c
   }
   h->split = keep_split;
   h->prefetch = keep_pf;
+}
+
+// Chain c's FIRST step of an episode, the deferred reset inside it (launch_step_fresh); false: not served.
+bool launch_chain_fresh(mt_handle h, const StepArgs& a0, uint32_t major, int chains, int c) {
+  const int64_t span = chain_span(h, chains), off = (int64_t)c * span;
+  if (off >= h->n) return true;
+  StepArgs as = args_for_range(h, a0, off, std::min(span, h->n - off));
+  as.major = major;
+  const int keep_split = h->split;
+  const bool keep_pf = h->prefetch;
+  h->split = h->chain_split;
+  h->prefetch = h->chain_prefetch;
+  const bool served = launch_step_fresh(h, as);
+  h->split = keep_split;
+  h->prefetch = keep_pf;
+  return served;
 }
 
 // Chain c's stream (chain 0 runs on the handle's own stream).
@@ -1719,16 +1764,26 @@ int mt_rollout(mt_handle h, int n_steps, uint64_t seed, uint32_t step_idx0) {
       }
       if (snap) a_last.snap = h->snap_row(sp);
     }
+    bool fresh_by_rollout_kernel = false;
     for (int st = 0; st < n_steps; ++st)
       for (int c = 0; c < chains; ++c) {
         h->stream = c == 0 ? root : h->chain_streams[c];
         const int64_t off = (int64_t)c * span;
         if (chained_fresh && st == 0 && off < h->n) {
-          // the episode's first step: ONE step of the rollout kernel with the deferred reset as its prologue (the state of
-          // reset_kernel + step_kernel, bit for bit: no reset launch, no re-fetch of what it would have written)
+          // the episode's first step carries the deferred reset as its prologue (the state of reset_kernel + step_kernel, bit
+          // for bit: no reset launch, no stores of what the step overwrites, no re-fetch of what the reset would have
+          // written): the step kernel's own FRESH form where the schedule has one, else ONE step of the rollout kernel
           if (rc == MT_OK) rc = order_behind_inplace_gather(h, h->stream);  // (the in-kernel reset writes MT_F_LAST_RETURN)
+          if (rc != MT_OK) continue;
+          StepArgs af = (n_steps == 1) ? a_last : a;
+          af.reset_seed_lo = (uint32_t)h->pend_seed;
+          af.reset_seed_hi = (uint32_t)(h->pend_seed >> 32);
+          af.reset_episode = h->pend_episode;
+          af.radius = h->cfg.radius;
+          if (launch_chain_fresh(h, af, step_idx0, chains, c)) continue;
+          fresh_by_rollout_kernel = true;
           const RolloutArgs r{1, step_idx0, 0u, h->cfg.radius, 1u, h->pend_episode, (uint32_t)h->pend_seed, (uint32_t)(h->pend_seed >> 32), nullptr};
-          if (rc == MT_OK) launch_rollout(h, args_for_range(h, a, off, std::min(span, h->n - off)), 1, r, h->rollout_early);
+          launch_rollout(h, args_for_range(h, a, off, std::min(span, h->n - off)), 1, r, h->rollout_early);
           continue;
         }
         if (rc == MT_OK) launch_chain(h, st == n_steps - 1 ? a_last : a, step_idx0 + (uint32_t)st, 1, chains, c);
@@ -1738,7 +1793,7 @@ int mt_rollout(mt_handle h, int n_steps, uint64_t seed, uint32_t step_idx0) {
     if (rc) return rc;
     rc = settle_chains(h);
     if (rc) return rc;
-    h->snap_valid = a_last.snap != nullptr && !(chained_fresh && n_steps == 1);
+    h->snap_valid = a_last.snap != nullptr && !(fresh_by_rollout_kernel && n_steps == 1);
   } else {
     for (int s = 0; s < n_steps; ++s) {
       int rc = mt_step_random(h, seed, step_idx0 + (uint32_t)s);

@@ -758,10 +758,23 @@ constexpr int kPrefetch = 8;
 //            Whole batch or a 256-aligned range of it only (threads past the end run up to the barrier: their loads stay
 //            inside the rows, which are ld >= round_up(n, 256) long); same bits as the computed values.
 //   FLAT   : the rows are addressed through LaneOffset<false> (see there): the HBM-bound launches of the prefetch kernel.
-template <class Tbl, bool SAMPLE, int TRIG, bool LDS, int PF = 0, bool TT = false, bool FLAT = false>
+__device__ __forceinline__ void draw_targets_wave(uint64_t seed, uint64_t env0, uint32_t episode, bool need, int K, float radius,
+                                                  float* col0, uint8_t* slots);
+
+//   FRESH  : the launch BEGINS with the full random reset mt_reset_random deferred to it (the chained launch-per-step form of
+//            mt_rollout, engine.hip): instead of loading pose / alive mask / return / targets the kernel keeps the finished
+//            return (MT_F_LAST_RETURN), starts from the zero pose with every target alive, stores the episode index, draws
+//            the targets with reset_kernel's wave-cooperative draw into LDS columns and writes them out -- reset_kernel's
+//            state, bit for bit, without its launch, without its stores of what this step overwrites anyway (pose, alive
+//            mask, return, end effector, reward, done: 41 B per env) and without this step's loads of what it would have
+//            written (108 B per env).  Dynamic LDS: [3K][kBlock] floats.
+template <class Tbl, bool SAMPLE, int TRIG, bool LDS, int PF = 0, bool TT = false, bool FLAT = false, bool FRESH = false>
 __global__ __launch_bounds__(kBlock, (PF ? 1 : step_min_waves<Tbl, TRIG>())) void step_kernel(const StepArgs a) {
   constexpr int D = Tbl::D;
   static_assert(!TT || (SAMPLE && TRIG == 0 && !LDS && ActionTrigTable<Tbl>::value), "the table serves sampled actions of a static table");
+  static_assert(!FRESH || TT, "the reset prologue exists for the sampled-action kernels of the static tables");
+  extern __shared__ float fresh_stage[];                          // FRESH: the drawn targets, [3K][kBlock]
+  __shared__ uint8_t fresh_slots[FRESH ? kBlock / 64 : 1][64];    // FRESH: draw_targets_wave's scratch
   __shared__ DhConst sh;
   __shared__ __attribute__((aligned(16))) SinCos trig_lds[TT ? kTrigEntries : 1];
   float4 trig_v;
@@ -776,7 +789,7 @@ __global__ __launch_bounds__(kBlock, (PF ? 1 : step_min_waves<Tbl, TRIG>())) voi
 
   const uint32_t i = blockIdx.x * kBlock + threadIdx.x;  // 32-bit lane offset: rows are addressed as uniform base + i
   LaneOffset<!FLAT> o4{i * 4u}, o1{i};  // byte offsets of this lane in the 32-bit rows / the byte rows
-  if (!TT && i >= a.n) return;
+  if (!TT && i >= a.n) return;  // (TT, and with it FRESH: every thread stays up to the barrier / takes part in the draw)
   const int64_t ld = a.ld;
   // Read ahead of every row access: behind one (its lane offset renewal is an opaque asm to the memory analysis) the
   // word is no longer provably unclobbered, and the s_load turns into a vector load with an s_waitcnt vmcnt(0) behind
@@ -789,9 +802,31 @@ __global__ __launch_bounds__(kBlock, (PF ? 1 : step_min_waves<Tbl, TRIG>())) voi
   MT_STAMP(a, i, 0);
   float g[D], act[D];
 #pragma unroll
-  for (int j = 0; j < D; ++j) g[j] = ldr(a.goals + j * ld, o4);
+  for (int j = 0; j < D; ++j) g[j] = FRESH ? 0.f : ldr(a.goals + j * ld, o4);
   float tx[PF ? PF : 1][3];
-  if (PF) {
+  if constexpr (FRESH) {
+    const bool mine = i < a.n;
+    const uint32_t lane = threadIdx.x & 63u;
+    if (mine) {
+      str(a.last_return, o4, ldr(a.total_reward, o4));  // what reset_kernel<.., RANDOM, false> keeps of the episode that ends here
+      str(a.episodes, o4, a.reset_episode);
+    }
+    draw_targets_wave(((uint64_t)a.reset_seed_hi << 32) | a.reset_seed_lo, (uint64_t)(a.env_base + (i - lane)), a.reset_episode, mine,
+                      a.K, a.radius, fresh_stage + (threadIdx.x - lane), fresh_slots[threadIdx.x >> 6]);
+    if (mine) {
+      const float* col = fresh_stage + threadIdx.x;
+#pragma unroll
+      for (int k = 0; k < (PF ? PF : 0); ++k)
+        if (k < a.K) {
+#pragma unroll
+          for (int q = 0; q < 3; ++q) {
+            tx[k][q] = col[(3 * k + q) * kBlock];
+            str(a.points + (int64_t)(3 * k + q) * ld, o4, tx[k][q]);
+          }
+        }
+      for (int r = 3 * PF; r < 3 * a.K; ++r) str(a.points + (int64_t)r * ld, o4, col[r * kBlock]);
+    }
+  } else if (PF) {
 #pragma unroll
     for (int k = 0; k < PF; ++k)
       if (k < a.K) {
@@ -808,7 +843,9 @@ __global__ __launch_bounds__(kBlock, (PF ? 1 : step_min_waves<Tbl, TRIG>())) voi
   // (Requesting the target rows here as well was measured: no gain, -2 waves/SIMD -- profiles/r01_variants.md.)
   uint32_t am = 0;
   float total_in = 0.f;
-  if (!kLean || PF) {
+  if (FRESH) {
+    am = (a.K >= 32) ? 0xFFFFFFFFu : ((1u << a.K) - 1u);
+  } else if (!kLean || PF) {
     am = ldr(a.alive, o4);
     total_in = ldr(a.total_reward, o4);
   }
@@ -845,7 +882,7 @@ __global__ __launch_bounds__(kBlock, (PF ? 1 : step_min_waves<Tbl, TRIG>())) voi
                                                             (a.flags & kFlagWholeGoals) != 0);
   const bool ground = zmin < 0.f;  // manytor.py:191
   if (a.zmin) str_stream(a.zmin, o4, zmin);  // MT_FLAG_DEBUG_ZMIN: wave-uniform branch on an SGPR pointer, NULL by default
-  if (kLean && !PF) {
+  if (kLean && !PF && !FRESH) {
     am = ldr(a.alive, o4);
     total_in = ldr(a.total_reward, o4);
   }

@@ -43,6 +43,10 @@ struct StepArgs {
   uint32_t* bad_actions;          // [1] number of (env, step) pairs whose staged action was not a usable angle
   const float* trig_table;        // [450][2] (sin, cos) of the whole degrees -270 .. 179, filled once at mt_create (kernels.h: SinCos)
   float* zmin;                    // [ld] MT_FLAG_DEBUG_ZMIN only (else NULL): the z-minimum the ground test of the last step used
+  // the first step launch of an episode (step_kernel<.., FRESH>): the deferred full reset it starts with -- the seed and
+  // the episode index of the target stream, the radius of the half ball
+  uint32_t reset_seed_lo, reset_seed_hi, reset_episode;
+  float radius;
   float* snap;                    // [n] NULL, or (the last step launch of an mt_rollout) the overlapped gather's snapshot row: the returns again
   uint32_t ring_slots, episode0;  // episode0 = episode index every env got at the last full reset
   int64_t n, ld, env_base;

@@ -10,8 +10,8 @@ import sys
 
 rows = []
 for r in csv.DictReader(open(sys.argv[1])):
-    rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0][-52:], int(r["Grid_Size_X"]),
-                 r.get("Queue_Id", "?")))
+    name = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("mt::", "")
+    rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), name[:64], int(r["Grid_Size_X"]), r.get("Queue_Id", "?")))
 rows.sort()
 roll = [r for r in rows if "rollout" in r[2]]
 if roll:
