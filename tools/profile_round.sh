@@ -10,7 +10,7 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/
 find "$out/trace" -name "*kernel_stats.csv" -exec cp {} "$out/kernel_stats.csv" \;
 head -12 "$out/kernel_stats.csv"
 trace_csv=$(find "$out/trace" -name "*kernel_trace.csv" | head -1)
-python3 tools/trace_summary.py "$trace_csv" --union "step_kernel<mt::Ref4Table, true, 0, false, 8, true, true>" 524288 2 > "$out/kernel_stats_by_grid.csv"
+python3 tools/trace_summary.py "$trace_csv" --union "step_kernel<mt::Ref4Table, true, 0, false, 8, true, true, false>" 524288 2 > "$out/kernel_stats_by_grid.csv"
 tail -1 "$out/kernel_stats_by_grid.csv"
 bash tools/pmc_step.sh "$out/pmc_d4" --no-secondary > "$out/pmc_d4.log" 2>&1 || echo "pmc d4 failed"
 bash tools/pmc_step.sh "$out/pmc_d7" --no-secondary --dof 7 > "$out/pmc_d7.log" 2>&1 || echo "pmc d7 failed"
