@@ -53,6 +53,18 @@ def test_bench_prints_one_contract_line():
     assert r["avg_kernel_us"] * 1e-3 <= d["device_ms_per_step"] <= d["ms_per_step"]
     assert d["value_device_timeline"] == pytest.approx(262144 / (d["device_ms_per_step"] * 1e-3), rel=1e-6)
     assert r["achievable_gbs"] > 2000 and r["achievable_gbs_same_size"] > 2000
+    # no figure called a fraction exceeds 1 anywhere in the line
+    def fractions(o, path=""):
+        if isinstance(o, dict):
+            for k, v in o.items():
+                yield from fractions(v, path + "/" + k)
+        elif isinstance(o, list):
+            for i, v in enumerate(o):
+                yield from fractions(v, f"{path}[{i}]")
+        elif isinstance(o, float) and "frac" in path.rsplit("/", 1)[-1]:
+            yield path, o
+    seen = list(fractions(d))
+    assert seen and all(0.0 <= v <= 1.0 for _, v in seen), [p_ for p_ in seen if not 0.0 <= p_[1] <= 1.0]
     c = d["cpu_baseline"]
     for key in ("value", "unit", "cores", "kind", "sample", "numpy_multiprocess_value", "numpy_multiprocess_cores"):
         assert key in c, key
