@@ -10,6 +10,33 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _fractions(o, path=""):
+    """(path, value) of every float in the line whose key names a fraction."""
+    if isinstance(o, dict):
+        for k, v in o.items():
+            yield from _fractions(v, path + "/" + k)
+    elif isinstance(o, list):
+        for i, v in enumerate(o):
+            yield from _fractions(v, f"{path}[{i}]")
+    elif isinstance(o, float) and "frac" in path.rsplit("/", 1)[-1]:
+        yield path, o
+
+
+@pytest.mark.gpu
+def test_bench_line_with_its_secondary_legs_holds_no_fraction_above_one():
+    """The whole line as the driver gets it (secondary configurations included; the CPU baseline skipped for time): every
+    key that names a fraction is one, also where the launches move less than SURVEY's model bytes (7-DoF table, k steps per
+    launch), where the model-bytes fraction is withheld instead of exceeding 1."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5",
+                          "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads(out.stdout)
+    seen = list(_fractions(d))
+    assert len(seen) > 10 and all(0.0 <= v <= 1.0 for _, v in seen), [p_ for p_ in seen if not 0.0 <= p_[1] <= 1.0]
+    cfg7 = [v for k, v in d["secondary"]["other_configs"].items() if "7-DoF" in k][0]
+    assert cfg7["survey_model_gbs"] > 0 and (cfg7["frac_survey_model"] is None or cfg7["frac_survey_model"] <= 1.0)
+
+
 @pytest.mark.gpu
 def test_bench_prints_one_contract_line():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5",
@@ -54,16 +81,7 @@ def test_bench_prints_one_contract_line():
     assert d["value_device_timeline"] == pytest.approx(262144 / (d["device_ms_per_step"] * 1e-3), rel=1e-6)
     assert r["achievable_gbs"] > 2000 and r["achievable_gbs_same_size"] > 2000
     # no figure called a fraction exceeds 1 anywhere in the line
-    def fractions(o, path=""):
-        if isinstance(o, dict):
-            for k, v in o.items():
-                yield from fractions(v, path + "/" + k)
-        elif isinstance(o, list):
-            for i, v in enumerate(o):
-                yield from fractions(v, f"{path}[{i}]")
-        elif isinstance(o, float) and "frac" in path.rsplit("/", 1)[-1]:
-            yield path, o
-    seen = list(fractions(d))
+    seen = list(_fractions(d))
     assert seen and all(0.0 <= v <= 1.0 for _, v in seen), [p_ for p_ in seen if not 0.0 <= p_[1] <= 1.0]
     c = d["cpu_baseline"]
     for key in ("value", "unit", "cores", "kind", "sample", "numpy_multiprocess_value", "numpy_multiprocess_cores"):
