@@ -56,6 +56,7 @@ sys.path.insert(0, ROOT)
 METRIC = "env-steps/sec (whole node), 1M parallel 4-DoF arms, random actions"
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
 MIN_TIMED_S = 0.25           # the repeated timed regions together cover at least this much GPU work (5..300 regions)
+LAP_EVERY = 4                   # bench.measure: every 4th timed region carries the HIP-event step laps (see there)
 PREWARM_S = 0.3
 F_LAST_RETURN = 12           # mt_field MT_F_LAST_RETURN (include/manytor_hip.h): the return an env had when it was last reset
 
@@ -303,9 +304,12 @@ class EpisodeLoop:
         self.gathers += 1
         self.eng.reset_random(self.seed, self.episode)
 
-    def run(self, count, time_kernels=False):
-        """`count` env steps.  Returns (step launches timed, gathers done) of this call."""
+    def run(self, count, time_kernels=False, laps=True):
+        """`count` env steps.  Returns (step launches timed, gathers done) of this call.  time_kernels: the calls are cut as a
+        timed region cuts them (an episode's first launch by itself); laps = False: the same calls WITHOUT the HIP-event laps
+        around them (bench.measure laps every LAP_EVERY-th region only: the stopwatch costs 7 us per lap, tools/lap_cost.py)."""
         done = launches = gathers = 0
+        lap = time_kernels and laps
         while done < count:
             seg = min(count - done, self.L - self.step % self.L)
             if time_kernels and self.head_steps and self.step % self.L == 0 and seg > self.head_steps:
@@ -315,16 +319,16 @@ class EpisodeLoop:
                 done += seg
                 self.head_launches += 1
                 if self.step % self.L == 0:
-                    self._episode_end(time_kernels)
+                    self._episode_end(lap)
                     gathers += 1
                 continue
-            if time_kernels:
+            if lap:
                 self.eng.lap_begin("step")      # HIP events on the engine's stream, no host synchronisation
             if self.fused:
                 self.eng.rollout_fused(seg, self.seed, self.step)
             else:
                 self.eng.rollout(seg, self.seed, self.step)
-            if time_kernels:
+            if lap:
                 self.eng.lap_end("step")
                 launches += seg
                 self.lap_steps.append(seg)
@@ -332,7 +336,7 @@ class EpisodeLoop:
             self.step += seg
             done += seg
             if self.step % self.L == 0:
-                self._episode_end(time_kernels)
+                self._episode_end(lap)
                 gathers += 1
         return launches, gathers
 
@@ -571,18 +575,26 @@ def measure(fab, raw, n_total, steps, warmup, episode_len, seed, fused=False, ov
     loop.align()                                                # the first timed region starts an episode
     fab.fence(raw)
     regions, device_ms, step_us_regions, gather_ms, launches, gathers = [], [], [], 0.0, 0, 0
-    for _ in range(reps):
+    # The step laps are a stopwatch INSIDE the timed work: an event record in front of and behind the launches of every lap,
+    # 7 us per lap (tools/lap_cost.py) -- 1 % of a 20-step region of 1 M arms, 10 % of one of a 131 072-arm shard (two laps).
+    # Every LAP_EVERY-th region carries them (same calls, same launches in all regions), the others run without.
+    lap_every = LAP_EVERY if reps >= 3 * LAP_EVERY else 1
+    lapped = []
+    for rep in range(reps):
+        with_laps = rep % lap_every == 0
         eng.start_region()
         fab.fence(raw)
         raw.timer_start()                                       # start mark on the idle device (ahead of the host clock)
         t0 = time.perf_counter()
-        ln, gt = loop.run(steps, time_kernels=True)
+        ln, gt = loop.run(steps, time_kernels=True, laps=with_laps)
         raw.timer_stop_async()                                  # end marks behind everything queued; no join, no host wait
         fab.fence(raw)
         regions.append(time.perf_counter() - t0)
         device_ms.append(raw.timer_read())
         ms = eng.collect()
-        step_us_regions.append(ms["step"] * 1e3 / max(1, ln))   # device time per step of THIS region (sum of its step laps)
+        lapped.append(with_laps)
+        if with_laps:
+            step_us_regions.append(ms["step"] * 1e3 / max(1, ln))   # device time per step of THIS region (sum of its step laps)
         # overlapped: device time of the region's last exchange on the side stream; in line: HIP-event laps around it
         gather_ms += (raw.gather_wait(host=True) * gt if gt else 0.0) if loop.overlap else ms["gather"]
         launches += ln
@@ -596,6 +608,8 @@ def measure(fab, raw, n_total, steps, warmup, episode_len, seed, fused=False, ov
     g = loop.gathered.cpu().numpy()
     assert np.all(g == np.round(g)) and np.abs(g).max() <= L    # returns of an L-step episode
     elapsed = float(np.median(regions))
+    lap_mask = np.asarray(lapped, dtype=bool)
+    elapsed_lapped = float(np.median(np.asarray(regions)[lap_mask]))     # the regions that carried the stopwatch
     dev_s = float(np.median(device_ms)) * 1e-3
     step_us = float(np.median(step_us_regions))                 # median over regions: one stalled lap does not move it
     return {"elapsed": elapsed, "ms_per_step": elapsed / steps * 1e3, "ms_per_step_min": float(regions.min()) / steps * 1e3,
@@ -606,7 +620,9 @@ def measure(fab, raw, n_total, steps, warmup, episode_len, seed, fused=False, ov
             "region_device_ms": dev_s * 1e3, "device_ms_per_step": dev_s * 1e3 / steps,
             "value_device_timeline": n_total * steps / max(dev_s, 1e-12),
             "steps_per_kernel_launch": launches / max(1, loop.kernel_launches),
-            "episode_first_launches_outside_laps": loop.head_launches, "episode_first_launch_steps": loop.head_steps}
+            "episode_first_launches_outside_laps": loop.head_launches, "episode_first_launch_steps": loop.head_steps,
+            "lapped_regions": int(lap_mask.sum()), "laps_every_nth_region": lap_every,
+            "ms_per_step_lapped_regions": elapsed_lapped / steps * 1e3}
 
 
 def self_launch(argv, gpus, dry_run=False, timeout_s=1800.0, script=None):
@@ -878,6 +894,7 @@ def main():
                "device_ms_per_step": r["device_ms_per_step"],
                "avg_kernel_us": r["step_us"], "kernel": name, "steps_per_kernel_launch": r["steps_per_kernel_launch"],
                "gather_us": r["gather_us"], "gathers_in_timed_region": r["gathers_per_region"], "repeats": r["repeats"],
+               "ms_per_step_lapped_regions": r["ms_per_step_lapped_regions"], "lapped_regions": r["lapped_regions"],
                "episode_len": r["episode_len"], "episode_phase": EpisodeLoop.phase % r["episode_len"],
                "collective": describe_collective(fallback), "gather_mode": gather_mode(fallback),
                # per-GPU fraction of the HBM peak while a step is on the device, on the bytes the launches really move
@@ -952,6 +969,13 @@ def main():
                        "targets": args.targets, "substeps": 25, "episode_len": L, "episode_phase": EpisodeLoop.phase % L,
                        "collective": describe_collective(gather_fallback),
                        "kernel_variant": variant, "prewarm_launches": r["prewarm"], "repeats": r["repeats"],
+                       "laps_every_nth_region": r["laps_every_nth_region"], "lapped_regions": r["lapped_regions"],
+                       "ms_per_step_lapped_regions": r["ms_per_step_lapped_regions"],
+                       "laps_note": "the HIP-event laps that time the step launches (roofline.avg_kernel_us) are a stopwatch inside "
+                                    "the timed work: an event record in front of and behind each lap's launches, 7 us per lap "
+                                    "(tools/lap_cost.py).  Every laps_every_nth_region-th region carries them, the others run the "
+                                    "same calls and launches without; ms_per_step / value are the median over ALL regions, "
+                                    "ms_per_step_lapped_regions the median of those with the stopwatch",
                        "gathers_in_timed_region": r["gathers_per_region"], "gather_mode": gather_mode(gather_fallback),
                        "launcher": os.environ.get("TORCHELASTIC_RUN_ID") and "torch.distributed.run" or
                                    ("bench.py self_launch (one fresh child process per rank)" if world > 1 else "none (one process)"),

@@ -326,7 +326,13 @@ def test_bench_episode_loop_world2_gloo(steps, warmup):
     assert launches == max(L, 200) + warmup + 3 * steps and resets == gathers + 1
 
 
-def _measure_worker(rank, world, port, steps, warmup, phase, q):
+def bench_lap_every():
+    sys.path.insert(0, ROOT)
+    import bench
+    return bench.LAP_EVERY
+
+
+def _measure_worker(rank, world, port, steps, warmup, phase, repeats, q):
     sys.path.insert(0, ROOT)
     import bench
     bench.EpisodeLoop.phase = phase                       # what main() sets from --episode-phase (N > 1: half an episode)
@@ -337,7 +343,7 @@ def _measure_worker(rank, world, port, steps, warmup, phase, q):
     for key, n_total in (("weak", 2 * 600), ("strong_1m", 1001), ("config3", 4003)):     # ragged strong shards
         eng = _FakeEngine(n_total, r, w)
         eng.tag_ids = False                               # bench.measure checks that returns are whole numbers
-        res = bench.measure(fab, eng, n_total, steps, warmup, 50, 0x5EED, prewarm_s=0.02, min_timed_s=0.001)
+        res = bench.measure(fab, eng, n_total, steps, warmup, 50, 0x5EED, prewarm_s=0.02, min_timed_s=0.001, repeats=repeats)
         out[key] = (res, eng.launches, eng.gathers)
     if r == 0:
         q.put(out)
@@ -346,18 +352,19 @@ def _measure_worker(rank, world, port, steps, warmup, phase, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("phase", [0, 10])
-def test_bench_measure_protocol_world2_gloo(phase):
+@pytest.mark.parametrize("phase,repeats", [(0, 0), (10, 0), (10, 17)])
+def test_bench_measure_protocol_world2_gloo(phase, repeats):
     """bench.measure + bench.Fabric -- the protocol every leg of an N > 1 invocation goes through (headline, the 1 M-arm
     strong leg, configs[3]) -- at world size 2 over gloo with the shared-memory barrier: every region launches exactly
     `steps` steps and contains a gather, the figures every leg reports are there, and both ranks agree on the number of
     regions (rank 0's clock decides the time-based loops).  phase = 10 is the N > 1 default: a region starts half-way
     through an episode, so its one gather sits in the middle of it."""
-    out = _spawn(_measure_worker, (20, 5, phase))
+    out = _spawn(_measure_worker, (20, 5, phase, repeats))
     for key, (res, launches, gathers) in out.items():
         for k in ("elapsed", "ms_per_step", "ms_per_step_min", "ms_per_step_max", "step_us", "launches", "gather_us",
                   "gathers_per_region", "repeats", "prewarm", "episode_len", "value", "value_device_timeline",
-                  "region_device_ms", "device_ms_per_step", "steps_per_kernel_launch"):
+                  "region_device_ms", "device_ms_per_step", "steps_per_kernel_launch", "lapped_regions",
+                  "laps_every_nth_region", "ms_per_step_lapped_regions"):
             assert k in res, (key, k)
         # the device timeline of a region: the stand-in reports 10 us per step between the start mark (after the opening
         # fence) and the end mark (before the closing one) -> exactly the region's 20 steps on both ranks
@@ -366,7 +373,13 @@ def test_bench_measure_protocol_world2_gloo(phase):
         assert res["value_device_timeline"] == pytest.approx(n_total * 20 / 0.2e-3)
         assert res["steps_per_kernel_launch"] == 1
         assert res["episode_len"] == 20 and res["gathers_per_region"] == 1 and res["repeats"] >= 5
-        assert res["launches"] == 20 * res["repeats"]
+        # the step laps ride in every region of a short run, in every 4th one of a long one (the stopwatch is not free);
+        # every region runs its 20 steps either way
+        if repeats:
+            assert res["repeats"] == repeats and res["laps_every_nth_region"] == bench_lap_every() and res["lapped_regions"] == 5
+        else:
+            assert res["laps_every_nth_region"] == 1 and res["lapped_regions"] == res["repeats"]
+        assert res["launches"] == 20 * res["lapped_regions"]
         assert launches == res["prewarm"] + 5 + phase + 20 * res["repeats"]
         assert res["ms_per_step_min"] <= res["ms_per_step"] <= res["ms_per_step_max"]
         # aligned after the warm-up, a 20-step region is ONE step segment = one 0.05 ms lap; started half-way through an

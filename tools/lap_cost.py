@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""What the HIP-event laps around the step launches cost a timed region in wall clock (1 048 576 arms, 20 steps + episode end,
-host timestamps around enqueue ... mt_sync + torch.cuda.synchronize, medians of 200 regions, interleaved).
-    python tools/lap_cost.py"""
+"""What the HIP-event laps around the step launches cost a timed region in wall clock (default 1 048 576 arms, 20 steps +
+episode end, host timestamps around enqueue ... mt_sync + torch.cuda.synchronize, medians of 200 regions, interleaved).
+    python tools/lap_cost.py [n_envs]"""
 import os
 import statistics
 import sys
@@ -12,7 +12,7 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 import manytor_amd as m  # noqa: E402
 
-n, k, T = 1048576, 7, 20
+n, k, T = (int(sys.argv[1]) if len(sys.argv) > 1 else 1048576), 7, 20
 e = m.StepEngine(n, k)
 e.reset_random(1, 0)
 for _ in range(30):
