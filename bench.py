@@ -36,6 +36,8 @@ is measured with HIP-event laps around the step launches only (mt_rollout may ru
 streams that stay forked across calls; a lap begins with the first of them and ends when the last of them does; `roofline`
 says so).  Where mt_rollout takes the episode's reset into its first launch (small shards), that launch -- another kernel --
 is issued as a rollout call of its own outside the laps, inside the region and its device timeline (EpisodeLoop.head_steps).
+The laps are a stopwatch inside the timed work (two event records per lap, 7 us): every LAP_EVERY-th region carries them, the
+others run the same calls without; `value` is the median over all regions, `config.ms_per_step_lapped_regions` beside it.
 
 Prints ONE JSON line on rank 0 (contract: see the task brief / DESIGN.md section "Measurement").
 """
